@@ -1,0 +1,144 @@
+"""ctypes binding of libhero_hip.so (C ABI declared in include/hero_hip.h).
+
+The product path has no CPU or PyTorch-eager fallback: if the shared library is missing, or a
+tensor is not a contiguous CUDA tensor, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhero_hip.so")
+
+F32, BF16 = 0, 1
+LAYOUT_K, LAYOUT_O = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_layernorm_fwd",
+    "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
+    "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len",
+    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast",
+    "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw",
+]
+
+
+class Dropout(C.Structure):
+    _fields_ = [("seed_ptr", C.c_void_p), ("site", C.c_uint64),
+                ("threshold16", C.c_uint32), ("scale", C.c_float)]
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
+                ("act", C.c_int), ("out_f32", C.c_int), ("beta", C.c_float),
+                ("split_k", C.c_int), ("dropout", Dropout)]
+
+
+class LnFwd(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("tab", C.c_void_p * 3), ("idx", C.c_void_p * 3),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p),
+                ("pre", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("eps", C.c_float),
+                ("x_dtype", C.c_int), ("y_dtype", C.c_int), ("dropout", Dropout)]
+
+
+class LnBwd(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("gamma", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dx", C.c_void_p),
+                ("dx_dropped", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("grad_beta", C.c_float), ("workspace", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("x_dtype", C.c_int), ("dtype", C.c_int),
+                ("dropout_out", Dropout), ("dropout_in", Dropout)]
+
+
+class Attn(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("mask", C.c_void_p), ("ctx", C.c_void_p),
+                ("probs", C.c_void_p), ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
+                ("S", C.c_int), ("L", C.c_int), ("H", C.c_int), ("scale", C.c_float),
+                ("dtype", C.c_int), ("dropout", Dropout)]
+
+
+class AdamW(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("n", C.c_size_t), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int),
+                ("grad_sumsq", C.c_void_p), ("max_grad_norm", C.c_float),
+                ("grad_scale", C.c_float), ("shadow", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "hero_amd: %s is missing. Build it with `python -m hero_amd.build` "
+                "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no fallback "
+                "path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.hero_last_error.restype = C.c_char_p
+        L.hero_layernorm_bwd_workspace_bytes.restype = C.c_size_t
+        L.hero_colsum_workspace_bytes.restype = C.c_size_t
+        L.hero_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [
+            C.POINTER(GemmEpilogue), C.c_void_p]
+        L.hero_layernorm_fwd.argtypes = [C.POINTER(LnFwd), C.c_void_p]
+        L.hero_layernorm_bwd.argtypes = [C.POINTER(LnBwd), C.c_void_p]
+        L.hero_layernorm_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        L.hero_colsum_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        L.hero_colsum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_float, C.c_void_p, C.c_void_p]
+        L.hero_attention_fwd.argtypes = [C.POINTER(Attn), C.c_void_p]
+        L.hero_attention_bwd.argtypes = [C.POINTER(Attn), C.c_void_p]
+        L.hero_attention_max_len.argtypes = [C.c_int, C.c_int]
+        L.hero_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hero_csr_gather_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hero_scatter_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hero_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.hero_relu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                    C.c_void_p]
+        L.hero_gelu_bwd.argtypes = L.hero_relu_bwd.argtypes
+        L.hero_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.hero_sumsq.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.hero_adamw.argtypes = [C.POINTER(AdamW), C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libhero_hip: %s (code %d)" % (lib().hero_last_error().decode(), rc))
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("hero_amd: unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("hero_amd: tensor is on %s; the HIP path needs CUDA/ROCm tensors and has "
+                           "no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("hero_amd: non-contiguous tensor passed to a HIP kernel")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def no_dropout():
+    return Dropout(None, 0, 0, 1.0)

@@ -1,0 +1,350 @@
+// Masked multi-head self-attention, head size 64, forward and backward (gfx950).
+//
+// HERO's sequences are short (a subtitle's frames+tokens: 10-40; a clip's frames: <= 100; the
+// long-video stress case: 256), so attention is < 1 % of the FLOPs of a layer and is bound by
+// launch count and HBM traffic, not by the matrix cores.  One workgroup (4 waves) owns one
+// (sequence, head): K and V of that head are staged once in LDS, every wave then walks query rows:
+//   scores : a key is owned by LPK adjacent lanes (LPK = 1/2/4 chosen from L so short sequences
+//            still fill the wave), each lane dots its 64/LPK slice of q (held in registers)
+//            with the K row in LDS, partial dots are combined with wave shuffles;
+//   softmax: row max / sum with wave shuffles over the per-wave score row in LDS;
+//   P.V    : lane d accumulates output column d over the keys (probability broadcast from LDS,
+//            V row read conflict-free).
+// The fp32 softmax output is written out for the backward pass (a few MB per layer at HERO's
+// lengths), the dropout mask is regenerated from the counter RNG.
+#include "common.h"
+
+namespace hero {
+
+constexpr int DH = 64;
+
+// LDS written by some lanes of a wave and read by other lanes of the SAME wave: the DS pipe is
+// in-order per wave, this only pins the compiler (and its s_waitcnt) at that point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T> struct KvLay;  // LDS row stride (elements) chosen odd in dwords -> conflict-free column walks
+template <> struct KvLay<float>  { static constexpr int STRIDE = 65; };
+template <> struct KvLay<bf16_t> { static constexpr int STRIDE = 66; };
+
+template <typename T>
+__device__ __forceinline__ void stage_head(const T* __restrict__ src, int ld, int L, T* dst, int stride) {
+  // src: first row of this head's [L, 64] slice (row stride ld). 16 lanes x 4 elements per row.
+  for (int q = threadIdx.x; q < L * 16; q += blockDim.x) {
+    const int r = q >> 4, c = (q & 15) * 4;
+    const float4 v = V4<T>::ld(src + (size_t)r * ld + c);
+    T* d = dst + r * stride + c;
+    st1<T>(d + 0, v.x); st1<T>(d + 1, v.y); st1<T>(d + 2, v.z); st1<T>(d + 3, v.w);
+  }
+}
+
+// dot of the register slice qv[0..DPL) with row `row` of an LDS matrix, columns [p*DPL, (p+1)*DPL)
+template <typename T, int DPL> __device__ __forceinline__ float dot_slice(const float (&qv)[DPL], const T* row_ptr);
+template <int DPL> __device__ __forceinline__ float dot_slice_f32(const float (&qv)[DPL], const float* rp) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < DPL; ++t) s = fmaf(qv[t], rp[t], s);
+  return s;
+}
+template <int DPL> __device__ __forceinline__ float dot_slice_bf16(const float (&qv)[DPL], const bf16_t* rp) {
+  float s = 0.f;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(rp);  // STRIDE 66 and DPL even keep this 4-byte aligned
+#pragma unroll
+  for (int t = 0; t < DPL / 2; ++t) {
+    const uint32_t u = w[t];
+    s = fmaf(qv[2 * t], __uint_as_float(u << 16), s);
+    s = fmaf(qv[2 * t + 1], __uint_as_float(u & 0xffff0000u), s);
+  }
+  return s;
+}
+template <typename T, int DPL> struct Dot;
+template <int DPL> struct Dot<float, DPL> {
+  static __device__ __forceinline__ float run(const float (&qv)[DPL], const float* rp) { return dot_slice_f32<DPL>(qv, rp); }
+};
+template <int DPL> struct Dot<bf16_t, DPL> {
+  static __device__ __forceinline__ float run(const float (&qv)[DPL], const bf16_t* rp) { return dot_slice_bf16<DPL>(qv, rp); }
+};
+
+// load a 64-wide row slice [p*DPL, (p+1)*DPL) from global into registers (same address across the
+// lanes that share p -> broadcast loads)
+template <typename T, int DPL>
+__device__ __forceinline__ void load_row_slice(const T* __restrict__ row, int p, float (&qv)[DPL]) {
+#pragma unroll
+  for (int t = 0; t < DPL; t += 4) {
+    const float4 v = V4<T>::ld(row + p * DPL + t);
+    qv[t] = v.x; qv[t + 1] = v.y; qv[t + 2] = v.z; qv[t + 3] = v.w;
+  }
+}
+
+template <typename T, int LPK>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DPL = DH / LPK, KPP = 64 / LPK, STR = KvLay<T>::STRIDE;
+  const int L = a.L, H = a.H, D = H * DH;
+  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Lp = (L + 3) & ~3;
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + (size_t)L * STR;
+  float* Ps = reinterpret_cast<float*>(smem + (((size_t)2 * L * STR * sizeof(T)) + 15) / 16 * 16) + wave * Lp;
+
+  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D;
+  stage_head<T>(qkv + D + h * DH, 3 * D, L, Ks, STR);
+  stage_head<T>(qkv + 2 * D + h * DH, 3 * D, L, Vs, STR);
+  __syncthreads();
+
+  const float* mask = a.mask ? a.mask + (size_t)s * L : nullptr;
+  DropCtx drop(a.dropout);
+  const int g = lane / LPK, p = lane % LPK;
+  T* ctx = static_cast<T*>(a.ctx) + (size_t)s * L * D + h * DH;
+  float* probs = a.probs ? a.probs + ((size_t)(s * H + h) * L) * L : nullptr;
+
+  for (int i = wave; i < L; i += 4) {
+    float qv[DPL];
+    load_row_slice<T, DPL>(qkv + (size_t)i * 3 * D + h * DH, p, qv);
+    // ---- scores
+    float mx = -3.0e38f;
+    for (int j0 = 0; j0 < L; j0 += KPP) {
+      const int j = j0 + g;
+      float sc = 0.f;
+      if (j < L) sc = Dot<T, DPL>::run(qv, Ks + j * STR + p * DPL);
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) sc += __shfl_xor(sc, o, 64);
+      if (j < L) {
+        sc = sc * a.scale + (mask ? mask[j] : 0.f);
+        if (p == 0) Ps[j] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    }
+    mx = wave_max(mx);
+    wave_lds_sync();
+    // ---- softmax (each lane owns keys lane, lane+64, ...)
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const float e = __expf(Ps[j] - mx);
+      Ps[j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < L; j += 64) {
+      float pr = Ps[j] * inv;
+      if (probs) probs[(size_t)i * L + j] = pr;
+      if (drop.on()) pr *= drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + j);
+      Ps[j] = pr;
+    }
+    wave_lds_sync();
+    // ---- context: lane = output column
+    float acc = 0.f;
+    int j = 0;
+    for (; j + 4 <= L; j += 4) {
+      const float4 pj = *reinterpret_cast<const float4*>(Ps + j);
+      acc = fmaf(pj.x, ld1<T>(Vs + (j + 0) * STR + lane), acc);
+      acc = fmaf(pj.y, ld1<T>(Vs + (j + 1) * STR + lane), acc);
+      acc = fmaf(pj.z, ld1<T>(Vs + (j + 2) * STR + lane), acc);
+      acc = fmaf(pj.w, ld1<T>(Vs + (j + 3) * STR + lane), acc);
+    }
+    for (; j < L; ++j) acc = fmaf(Ps[j], ld1<T>(Vs + j * STR + lane), acc);
+    st1<T>(ctx + (size_t)i * D + lane, acc);
+    wave_lds_sync();  // Ps is rewritten by the next row
+  }
+}
+
+// Backward. LDS: K, V (padded stride), Q, dO (stride 64), and for a chunk of R query rows the
+// matrices dS[R][Lp] (already scaled) and Pd[R][Lp] (dropped probabilities).  dK/dV accumulate in
+// registers across chunks: wave w owns keys w, w+4, ... (KPW of them per wave).
+template <typename T, int LPK, int KPW>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DPL = DH / LPK, KPP = 64 / LPK, STR = KvLay<T>::STRIDE;
+  const int L = a.L, H = a.H, D = H * DH;
+  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Lp = (L + 3) & ~3;
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + (size_t)L * STR;
+  T* Qs = Vs + (size_t)L * STR;
+  T* Os = Qs + (size_t)L * DH;
+  float* dS = reinterpret_cast<float*>(smem + (((size_t)(2 * L * STR + 2 * L * DH) * sizeof(T)) + 15) / 16 * 16);
+  float* Pd = dS + (size_t)R * Lp;
+
+  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D;
+  const T* dctx = static_cast<const T*>(a.dctx) + (size_t)s * L * D + h * DH;
+  stage_head<T>(qkv + h * DH, 3 * D, L, Qs, DH);
+  stage_head<T>(qkv + D + h * DH, 3 * D, L, Ks, STR);
+  stage_head<T>(qkv + 2 * D + h * DH, 3 * D, L, Vs, STR);
+  stage_head<T>(dctx, D, L, Os, DH);
+  __syncthreads();
+
+  DropCtx drop(a.dropout);
+  const int g = lane / LPK, p = lane % LPK;
+  const float* probs = a.probs + ((size_t)(s * H + h) * L) * L;
+  T* dqkv = static_cast<T*>(a.dqkv) + (size_t)s * L * 3 * D;
+
+  float accK[KPW], accV[KPW];
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) { accK[k] = 0.f; accV[k] = 0.f; }
+
+  for (int c0 = 0; c0 < L; c0 += R) {
+    const int cr = min(R, L - c0);
+    // ---- phase A: rows of this chunk -> dS, Pd in LDS, dQ to HBM
+    for (int il = wave; il < cr; il += 4) {
+      const int i = c0 + il;
+      float ov[DPL];
+      load_row_slice<T, DPL>(dctx + (size_t)i * D, p, ov);
+      float* dSr = dS + (size_t)il * Lp;
+      float* Pdr = Pd + (size_t)il * Lp;
+      float delta = 0.f;
+      for (int j0 = 0; j0 < L; j0 += KPP) {
+        const int j = j0 + g;
+        float dp = 0.f;
+        if (j < L) dp = Dot<T, DPL>::run(ov, Vs + j * STR + p * DPL);
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) dp += __shfl_xor(dp, o, 64);
+        if (j < L && p == 0) {
+          const float pr = probs[(size_t)i * L + j];
+          const float m = drop.on() ? drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + j) : 1.f;
+          dp *= m;                 // dP_ij
+          Pdr[j] = pr * m;         // dropped probability (feeds dV)
+          dSr[j] = dp;             // temporarily dP
+          delta += dp * pr;
+        }
+      }
+      delta = wave_sum(delta);
+      wave_lds_sync();
+      for (int j = lane; j < L; j += 64) {
+        const float pr = probs[(size_t)i * L + j];
+        dSr[j] = pr * (dSr[j] - delta) * a.scale;
+      }
+      wave_lds_sync();
+      // dQ[i][lane] = sum_j dS_ij K[j][lane]
+      float acc = 0.f;
+      for (int j = 0; j < L; ++j) acc = fmaf(dSr[j], ld1<T>(Ks + j * STR + lane), acc);
+      st1<T>(dqkv + (size_t)i * 3 * D + h * DH + lane, acc);
+    }
+    __syncthreads();
+    // ---- phase B: keys owned by this wave accumulate over the chunk's rows
+#pragma unroll
+    for (int k = 0; k < KPW; ++k) {
+      const int j = wave + 4 * k;
+      if (j < L) {
+        float ak = accK[k], av = accV[k];
+        for (int il = 0; il < cr; ++il) {
+          const int i = c0 + il;
+          ak = fmaf(dS[(size_t)il * Lp + j], ld1<T>(Qs + i * DH + lane), ak);
+          av = fmaf(Pd[(size_t)il * Lp + j], ld1<T>(Os + i * DH + lane), av);
+        }
+        accK[k] = ak; accV[k] = av;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < KPW; ++k) {
+    const int j = wave + 4 * k;
+    if (j < L) {
+      st1<T>(dqkv + (size_t)j * 3 * D + D + h * DH + lane, accK[k]);
+      st1<T>(dqkv + (size_t)j * 3 * D + 2 * D + h * DH + lane, accV[k]);
+    }
+  }
+}
+
+constexpr size_t LDS_BUDGET = 150 * 1024;
+
+template <typename T> static size_t fwd_lds(int L) {
+  const int Lp = (L + 3) & ~3;
+  return (((size_t)2 * L * KvLay<T>::STRIDE * sizeof(T)) + 15) / 16 * 16 + (size_t)4 * Lp * sizeof(float);
+}
+template <typename T> static size_t bwd_lds_fixed(int L) {
+  return (((size_t)(2 * L * KvLay<T>::STRIDE + 2 * L * DH) * sizeof(T)) + 15) / 16 * 16;
+}
+template <typename T> static int max_len(int backward) {
+  int L = 1;
+  if (!backward) {
+    while (L < 1024 && fwd_lds<T>(L + 1) <= LDS_BUDGET) ++L;
+    return L;
+  }
+  while (L < 256 && bwd_lds_fixed<T>(L + 1) + (size_t)2 * 4 * ((L + 4) & ~3) * sizeof(float) <= LDS_BUDGET) ++L;
+  return L;
+}
+
+template <typename T, int LPK>
+static int launch_fwd(const HeroAttn& a, hipStream_t s) {
+  const size_t lds = fwd_lds<T>(a.L);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET);
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
+  return check_launch("hero_attention_fwd");
+}
+template <typename T, int LPK, int KPW>
+static int launch_bwd(const HeroAttn& a, hipStream_t s) {
+  const int Lp = (a.L + 3) & ~3;
+  const size_t fixed = bwd_lds_fixed<T>(a.L);
+  int R = (int)((LDS_BUDGET - fixed) / ((size_t)2 * Lp * sizeof(float)));
+  if (R > a.L) R = a.L;
+  R &= ~3;
+  if (R < 4) R = a.L < 4 ? a.L : 4;
+  const size_t lds = fixed + (size_t)2 * R * Lp * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, LPK, KPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET + 8192));
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_kernel<T, LPK, KPW>), dim3(a.S * a.H), dim3(256), lds, s, a, R);
+  return check_launch("hero_attention_bwd");
+}
+template <typename T, int LPK>
+static int bwd_by_len(const HeroAttn& a, hipStream_t s) {
+  if (a.L <= 32) return launch_bwd<T, LPK, 8>(a, s);
+  if (a.L <= 64) return launch_bwd<T, LPK, 16>(a, s);
+  if (a.L <= 128) return launch_bwd<T, LPK, 32>(a, s);
+  return launch_bwd<T, LPK, 64>(a, s);
+}
+template <typename T>
+static int run(const HeroAttn& a, bool bwd, hipStream_t s) {
+  const int lim = max_len<T>(bwd ? 1 : 0);
+  if (a.L > lim) {
+    set_error("hero_attention_%s: sequence length %d exceeds the LDS-resident limit %d for this dtype", bwd ? "bwd" : "fwd", a.L, lim);
+    return HERO_ERR_UNSUPPORTED;
+  }
+  if (a.L <= 16) return bwd ? bwd_by_len<T, 4>(a, s) : launch_fwd<T, 4>(a, s);
+  if (a.L <= 32) return bwd ? bwd_by_len<T, 2>(a, s) : launch_fwd<T, 2>(a, s);
+  return bwd ? bwd_by_len<T, 1>(a, s) : launch_fwd<T, 1>(a, s);
+}
+
+}  // namespace hero
+
+using namespace hero;
+
+static int check_attn(const HeroAttn* a, bool bwd) {
+  HERO_REQUIRE(a && a->qkv, "hero_attention: null qkv");
+  HERO_REQUIRE(a->S >= 0 && a->L > 0 && a->H > 0, "hero_attention: bad dims S=%d L=%d H=%d", a->S, a->L, a->H);
+  HERO_REQUIRE(a->dtype == HERO_F32 || a->dtype == HERO_BF16, "hero_attention: bad dtype %d", a->dtype);
+  if (bwd) HERO_REQUIRE(a->probs && a->dctx && a->dqkv, "hero_attention_bwd: probs/dctx/dqkv required");
+  else HERO_REQUIRE(a->ctx, "hero_attention_fwd: ctx required");
+  return HERO_OK;
+}
+
+extern "C" int hero_attention_fwd(const HeroAttn* a, hero_stream_t stream) {
+  int rc = check_attn(a, false);
+  if (rc) return rc;
+  if (a->S == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return a->dtype == HERO_BF16 ? run<bf16_t>(*a, false, s) : run<float>(*a, false, s);
+}
+extern "C" int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream) {
+  int rc = check_attn(a, true);
+  if (rc) return rc;
+  if (a->S == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return a->dtype == HERO_BF16 ? run<bf16_t>(*a, true, s) : run<float>(*a, true, s);
+}
+extern "C" int hero_attention_max_len(int dtype, int backward) {
+  return dtype == HERO_BF16 ? max_len<bf16_t>(backward) : max_len<float>(backward);
+}

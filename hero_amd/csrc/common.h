@@ -1,0 +1,110 @@
+// Shared device helpers for the hero_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hero_hip.h"
+
+namespace hero {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// ---- 4-element vector access in the activation dtype ----------------------------------------
+template <typename T> struct V4;
+template <> struct V4<float> {
+  static __device__ __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct V4<bf16_t> {
+  static __device__ __forceinline__ float4 ld(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+};
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---- counter-based dropout -------------------------------------------------------------------
+// One splitmix64 draw yields four 16-bit uniforms = the keep decisions of 4 consecutive elements.
+// The same (seed word, site, group index) is replayed by the backward kernels, so no mask is stored.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+struct DropCtx {
+  uint64_t base;
+  uint32_t thr;
+  float scale;
+  __device__ __forceinline__ DropCtx(const HeroDropout& d) {
+    thr = d.threshold16;
+    scale = d.scale;
+    base = thr ? splitmix64((d.seed_ptr ? *d.seed_ptr : 0ull) ^ (d.site * 0xD6E8FEB86659FD93ull)) : 0ull;
+  }
+  __device__ __forceinline__ bool on() const { return thr != 0; }
+  // group = index of a 4-element group; returns per-element multipliers (0 or scale)
+  __device__ __forceinline__ float4 mask4(uint64_t group) const {
+    uint64_t r = splitmix64(base + group * 0x9E3779B97F4A7C15ull);
+    float4 m;
+    m.x = ((uint32_t)(r & 0xffff) >= thr) ? scale : 0.f;
+    m.y = ((uint32_t)((r >> 16) & 0xffff) >= thr) ? scale : 0.f;
+    m.z = ((uint32_t)((r >> 32) & 0xffff) >= thr) ? scale : 0.f;
+    m.w = ((uint32_t)(r >> 48) >= thr) ? scale : 0.f;
+    return m;
+  }
+  __device__ __forceinline__ float mask1(uint64_t elem) const {
+    uint64_t r = splitmix64(base + (elem >> 2) * 0x9E3779B97F4A7C15ull);
+    return ((uint32_t)((r >> (16 * (elem & 3))) & 0xffff) >= thr) ? scale : 0.f;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// error plumbing (api.cpp)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define HERO_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      ::hero::set_error(__VA_ARGS__);  \
+      return HERO_ERR_ARG;             \
+    }                                  \
+  } while (0)
+
+}  // namespace hero

@@ -1,0 +1,322 @@
+// LayerNorm forward / backward (HBM-bound) for gfx950.
+//
+// forward : one 64-lane wave per row, the whole row lives in registers (VPL float4 per lane),
+//           exact two-pass statistics in fp32, optional gathered embedding-table rows added in
+//           front (SubEmbeddings / ImageEmbeddings / FrameEmbeddings sums) and dropout behind.
+// backward: dx with the same row-in-registers scheme; dgamma/dbeta and plain bias gradients by a
+//           two-stage deterministic column reduction (partials in a caller workspace, no atomics).
+#include "common.h"
+
+namespace hero {
+
+template <typename TX, typename TY, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(HeroLnFwd a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const int cols = a.cols;
+  const TX* x = a.x ? static_cast<const TX*>(a.x) + (size_t)row * cols : nullptr;
+  const float* t[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    t[k] = a.tab[k] ? a.tab[k] + (size_t)(a.idx[k] ? a.idx[k][row] : 0) * cols : nullptr;
+
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+      if (x) u = V4<TX>::ld(x + c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (t[k]) {
+          const float4 w = *reinterpret_cast<const float4*>(t[k] + c);
+          u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+        }
+      s += (u.x + u.y) + (u.z + u.w);
+    }
+    v[i] = u;
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+  DropCtx drop(a.dropout);
+  TY* y = static_cast<TY*>(a.y) + (size_t)row * cols;
+  TY* pre = a.pre ? static_cast<TY*>(a.pre) + (size_t)row * cols : nullptr;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      if (pre) V4<TY>::st(pre + c, v[i]);
+      const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(a.beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (drop.on()) {
+        const float4 m = drop.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
+        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+      }
+      V4<TY>::st(y + c, o);
+    }
+  }
+}
+
+template <typename TX, typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(HeroLnBwd a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const int cols = a.cols;
+  const TX* x = static_cast<const TX*>(a.x) + (size_t)row * cols;
+  const T* dy = static_cast<const T*>(a.dy) + (size_t)row * cols;
+  const float mean = a.mean[row], rstd = a.rstd[row];
+  DropCtx dout(a.dropout_out);
+  float4 xh[VPL], g[VPL];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g[i] = xh[i];
+    if (c < cols) {
+      const float4 xv = V4<TX>::ld(x + c);
+      float4 d = V4<T>::ld(dy + c);
+      if (dout.on()) {
+        const float4 m = dout.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
+        d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+      }
+      const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c);
+      xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+    }
+  }
+  const float inv = 1.f / (float)cols;
+  s1 = wave_sum(s1) * inv;
+  s2 = wave_sum(s2) * inv;
+  DropCtx din(a.dropout_in);
+  T* dx = a.dx ? static_cast<T*>(a.dx) + (size_t)row * cols : nullptr;
+  T* dxd = a.dx_dropped ? static_cast<T*>(a.dx_dropped) + (size_t)row * cols : nullptr;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      float4 o;
+      o.x = rstd * (g[i].x - s1 - xh[i].x * s2);
+      o.y = rstd * (g[i].y - s1 - xh[i].y * s2);
+      o.z = rstd * (g[i].z - s1 - xh[i].z * s2);
+      o.w = rstd * (g[i].w - s1 - xh[i].w * s2);
+      if (dx) V4<T>::st(dx + c, o);
+      if (dxd) {
+        if (din.on()) {
+          const float4 m = din.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
+          o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+        }
+        V4<T>::st(dxd + c, o);
+      }
+    }
+  }
+}
+
+// partial column sums over a chunk of rows.  pb[chunk][c] = sum dy_eff ; pg[chunk][c] = sum dy_eff*xhat
+struct ColRed {
+  const void* x;      // [rows, cols] TX or null
+  const void* dy;     // [rows, ld]  T
+  const float* mean;
+  const float* rstd;
+  float* pg;
+  float* pb;
+  int rows, cols, ld, rows_per_chunk;
+  HeroDropout dropout;
+};
+
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void colred_kernel(ColRed a) {
+  __shared__ float4 red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + tx) * 4;
+  const int chunk = blockIdx.y;
+  const int r0 = chunk * a.rows_per_chunk;
+  const int r1 = min(a.rows, r0 + a.rows_per_chunk);
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+  if (c < a.cols) {
+    DropCtx drop(a.dropout);
+    const TX* x = static_cast<const TX*>(a.x);
+    const T* dy = static_cast<const T*>(a.dy);
+    for (int r = r0 + ty; r < r1; r += 4) {
+      float4 d = V4<T>::ld(dy + (size_t)r * a.ld + c);
+      if (drop.on()) {
+        const float4 m = drop.mask4(((uint64_t)r * (uint64_t)a.cols + (uint64_t)c) >> 2);
+        d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+      }
+      sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+      if (x) {
+        const float4 xv = V4<TX>::ld(x + (size_t)r * a.cols + c);
+        const float mu = a.mean[r], rs = a.rstd[r];
+        sg.x += d.x * (xv.x - mu) * rs; sg.y += d.y * (xv.y - mu) * rs;
+        sg.z += d.z * (xv.z - mu) * rs; sg.w += d.w * (xv.w - mu) * rs;
+      }
+    }
+  }
+  red[0][ty][tx] = sg;
+  red[1][ty][tx] = sb;
+  __syncthreads();
+  if (ty == 0 && c < a.cols) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 g2 = red[0][k][tx], b2 = red[1][k][tx];
+      sg.x += g2.x; sg.y += g2.y; sg.z += g2.z; sg.w += g2.w;
+      sb.x += b2.x; sb.y += b2.y; sb.z += b2.z; sb.w += b2.w;
+    }
+    if (a.pg) *reinterpret_cast<float4*>(a.pg + (size_t)chunk * a.cols + c) = sg;
+    *reinterpret_cast<float4*>(a.pb + (size_t)chunk * a.cols + c) = sb;
+  }
+}
+
+__global__ void colred_final_kernel(const float* pg, const float* pb, float* og, float* ob, int cols, int nchunks, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float sg = 0.f, sb = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    if (og) sg += pg[(size_t)k * cols + c];
+    if (ob) sb += pb[(size_t)k * cols + c];
+  }
+  if (og) og[c] = (beta != 0.f ? beta * og[c] : 0.f) + sg;
+  if (ob) ob[c] = (beta != 0.f ? beta * ob[c] : 0.f) + sb;
+}
+
+static inline int chunking(int rows, int* rpc) {
+  int r = (rows + 255) / 256;
+  if (r < 16) r = 16;
+  *rpc = r;
+  return (rows + r - 1) / r;
+}
+
+template <typename TX, typename T>
+static int run_colred(const void* x, const void* dy, const float* mean, const float* rstd, float* og, float* ob, int rows,
+                      int cols, int ld, float beta, const HeroDropout& dr, void* ws, hipStream_t s) {
+  ColRed a;
+  a.x = x; a.dy = dy; a.mean = mean; a.rstd = rstd;
+  a.rows = rows; a.cols = cols; a.ld = ld; a.dropout = dr;
+  const int nchunks = chunking(rows, &a.rows_per_chunk);
+  a.pb = static_cast<float*>(ws);
+  a.pg = x ? a.pb + (size_t)nchunks * cols : nullptr;
+  hipLaunchKernelGGL((colred_kernel<TX, T>), dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, a);
+  int rc = check_launch("colred");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
+                     nchunks, beta);
+  return check_launch("colred_final");
+}
+
+#define HERO_VPL_SWITCH(cols, CALL)                                        \
+  do {                                                                     \
+    const int need = ((cols) + 255) / 256;                                 \
+    if (need <= 1) { CALL(1); }                                            \
+    else if (need <= 2) { CALL(2); }                                       \
+    else if (need <= 3) { CALL(3); }                                       \
+    else if (need <= 4) { CALL(4); }                                       \
+    else if (need <= 6) { CALL(6); }                                       \
+    else if (need <= 8) { CALL(8); }                                       \
+    else if (need <= 12) { CALL(12); }                                     \
+    else if (need <= 17) { CALL(17); }                                     \
+    else if (need <= 24) { CALL(24); }                                     \
+    else { set_error("layernorm: cols %d too wide (max 6144)", (cols)); return HERO_ERR_UNSUPPORTED; } \
+  } while (0)
+
+}  // namespace hero
+
+using namespace hero;
+
+extern "C" int hero_layernorm_fwd(const HeroLnFwd* a, hero_stream_t stream) {
+  HERO_REQUIRE(a && a->y && a->gamma && a->beta, "hero_layernorm_fwd: null pointer");
+  HERO_REQUIRE(a->x || a->tab[0] || a->tab[1] || a->tab[2], "hero_layernorm_fwd: no input");
+  HERO_REQUIRE(a->cols > 0 && a->cols % 4 == 0, "hero_layernorm_fwd: cols (%d) must be a positive multiple of 4", a->cols);
+  if (a->rows <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((a->rows + 3) / 4), block(256);
+  const int xd = a->x ? a->x_dtype : a->y_dtype, yd = a->y_dtype;
+#define CALL(V)                                                                                                   \
+  if (xd == HERO_F32 && yd == HERO_F32) hipLaunchKernelGGL((ln_fwd_kernel<float, float, V>), grid, block, 0, s, *a);        \
+  else if (xd == HERO_F32 && yd == HERO_BF16) hipLaunchKernelGGL((ln_fwd_kernel<float, bf16_t, V>), grid, block, 0, s, *a); \
+  else if (xd == HERO_BF16 && yd == HERO_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, bf16_t, V>), grid, block, 0, s, *a); \
+  else { set_error("hero_layernorm_fwd: unsupported dtypes x=%d y=%d", xd, yd); return HERO_ERR_UNSUPPORTED; }
+  HERO_VPL_SWITCH(a->cols, CALL);
+#undef CALL
+  return check_launch("hero_layernorm_fwd");
+}
+
+extern "C" size_t hero_layernorm_bwd_workspace_bytes(int rows, int cols) {
+  (void)rows;
+  return (size_t)256 * (size_t)cols * 2 * sizeof(float);
+}
+extern "C" size_t hero_colsum_workspace_bytes(int rows, int cols) {
+  (void)rows;
+  return (size_t)256 * (size_t)cols * sizeof(float);
+}
+
+extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
+  HERO_REQUIRE(a && a->x && a->dy && a->gamma && a->mean && a->rstd, "hero_layernorm_bwd: null pointer");
+  HERO_REQUIRE(a->cols > 0 && a->cols % 4 == 0, "hero_layernorm_bwd: cols (%d) must be a positive multiple of 4", a->cols);
+  if (a->rows <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int xd = a->x_dtype, d = a->dtype;
+  if (a->dx || a->dx_dropped) {
+    const dim3 grid((a->rows + 3) / 4), block(256);
+#define CALL(V)                                                                                                      \
+  if (xd == HERO_F32 && d == HERO_F32) hipLaunchKernelGGL((ln_bwd_dx_kernel<float, float, V>), grid, block, 0, s, *a);          \
+  else if (xd == HERO_F32 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_dx_kernel<float, bf16_t, V>), grid, block, 0, s, *a);   \
+  else if (xd == HERO_BF16 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, bf16_t, V>), grid, block, 0, s, *a); \
+  else { set_error("hero_layernorm_bwd: unsupported dtypes x=%d dy=%d", xd, d); return HERO_ERR_UNSUPPORTED; }
+    HERO_VPL_SWITCH(a->cols, CALL);
+#undef CALL
+    int rc = check_launch("hero_layernorm_bwd(dx)");
+    if (rc) return rc;
+  }
+  if (a->dgamma || a->dbeta) {
+    HERO_REQUIRE(a->workspace, "hero_layernorm_bwd: workspace required for dgamma/dbeta");
+    if (xd == HERO_F32 && d == HERO_F32)
+      return run_colred<float, float>(a->x, a->dy, a->mean, a->rstd, a->dgamma, a->dbeta, a->rows, a->cols, a->cols, a->grad_beta, a->dropout_out, a->workspace, s);
+    if (xd == HERO_F32 && d == HERO_BF16)
+      return run_colred<float, bf16_t>(a->x, a->dy, a->mean, a->rstd, a->dgamma, a->dbeta, a->rows, a->cols, a->cols, a->grad_beta, a->dropout_out, a->workspace, s);
+    if (xd == HERO_BF16 && d == HERO_BF16)
+      return run_colred<bf16_t, bf16_t>(a->x, a->dy, a->mean, a->rstd, a->dgamma, a->dbeta, a->rows, a->cols, a->cols, a->grad_beta, a->dropout_out, a->workspace, s);
+    set_error("hero_layernorm_bwd: unsupported dtypes x=%d dy=%d", xd, d);
+    return HERO_ERR_UNSUPPORTED;
+  }
+  return HERO_OK;
+}
+
+extern "C" int hero_colsum(const void* x, float* out, int rows, int cols, int ld, int dtype, float beta, void* workspace,
+                           hero_stream_t stream) {
+  HERO_REQUIRE(x && out && workspace, "hero_colsum: null pointer");
+  HERO_REQUIRE(cols > 0 && cols % 4 == 0 && ld % 4 == 0, "hero_colsum: cols/ld (%d, %d) must be multiples of 4", cols, ld);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HeroDropout none = {nullptr, 0, 0, 1.f};
+  if (rows <= 0) {
+    if (beta == 0.f) hipMemsetAsync(out, 0, sizeof(float) * cols, s);
+    return HERO_OK;
+  }
+  if (dtype == HERO_F32) return run_colred<float, float>(nullptr, x, nullptr, nullptr, nullptr, out, rows, cols, ld, beta, none, workspace, s);
+  if (dtype == HERO_BF16) return run_colred<float, bf16_t>(nullptr, x, nullptr, nullptr, nullptr, out, rows, cols, ld, beta, none, workspace, s);
+  set_error("hero_colsum: bad dtype %d", dtype);
+  return HERO_ERR_ARG;
+}

@@ -1,0 +1,291 @@
+// Row gathers / scatters, elementwise helpers and the fused optimiser (all HBM-bound, gfx950).
+#include "common.h"
+
+namespace hero {
+
+// ---- out[r] = a[idx] | 0 | b[-idx-2] -----------------------------------------------------------
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, const int32_t* __restrict__ idx,
+                                   T* __restrict__ out, int rows, int cols) {
+  const int c4n = cols >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < (size_t)rows * c4n; q += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(q / c4n), c = (int)(q - (size_t)r * c4n) * 4;
+    const int i = idx[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= 0) v = V4<T>::ld(a + (size_t)i * cols + c);
+    else if (i <= -2) v = V4<T>::ld(b + (size_t)(-i - 2) * cols + c);
+    V4<T>::st(out + (size_t)r * cols + c, v);
+  }
+}
+
+// ---- out[r] = sum over CSR entries ---------------------------------------------------------------
+template <typename T>
+__global__ void csr_gather_sum_kernel(const T* __restrict__ src, const int32_t* __restrict__ offs,
+                                      const int32_t* __restrict__ ent, T* __restrict__ out, int rows, int cols) {
+  const int c4n = cols >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < (size_t)rows * c4n; q += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(q / c4n), c = (int)(q - (size_t)r * c4n) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = offs[r]; e < offs[r + 1]; ++e) {
+      const float4 w = V4<T>::ld(src + (size_t)ent[e] * cols + c);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    V4<T>::st(out + (size_t)r * cols + c, v);
+  }
+}
+
+// ---- dst[idx[r]] += src[r] -------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add2(float* p, float x, float y) {
+  atomicAdd(p, x);
+  atomicAdd(p + 1, y);
+}
+__device__ __forceinline__ void atomic_add2(bf16_t* p, float x, float y) {  // p is 4-byte aligned (even column)
+  uint32_t* w = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = *w, assumed;
+  do {
+    assumed = old;
+    const float lo = __uint_as_float(assumed << 16) + x;
+    const float hi = __uint_as_float(assumed & 0xffff0000u) + y;
+    const uint32_t nw = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    old = atomicCAS(w, assumed, nw);
+  } while (old != assumed);
+}
+
+template <typename TS, typename TD>
+__global__ void scatter_add_rows_kernel(const TS* __restrict__ src, const int32_t* __restrict__ idx, TD* dst_a, TD* dst_b,
+                                        int rows, int cols, int skip) {
+  const int c2n = cols >> 1;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < (size_t)rows * c2n; q += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(q / c2n), c = (int)(q - (size_t)r * c2n) * 2;
+    const int i = idx[r];
+    if (i == -1 || i == skip) continue;
+    const float x = ld1<TS>(src + (size_t)r * cols + c), y = ld1<TS>(src + (size_t)r * cols + c + 1);
+    if (x == 0.f && y == 0.f) continue;
+    TD* d = i >= 0 ? dst_a + (size_t)i * cols + c : (dst_b ? dst_b + (size_t)(-i - 2) * cols + c : nullptr);
+    if (d) atomic_add2(d, x, y);
+  }
+}
+
+// ---- elementwise -------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x)
+    V4<TD>::st(d + q * 4, V4<TS>::ld(s + q * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1<TD>(d + n4 * 4 + threadIdx.x, ld1<TS>(s + n4 * 4 + threadIdx.x));
+}
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+    float4 g = V4<T>::ld(dy + q * 4);
+    const float4 v = V4<T>::ld(y + q * 4);
+    g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f; g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
+    V4<T>::st(dx + q * 4, g);
+  }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u, T* __restrict__ dx, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+    float4 g = V4<T>::ld(dy + q * 4);
+    const float4 v = V4<T>::ld(u + q * 4);
+    g.x *= gelu_erf_grad(v.x); g.y *= gelu_erf_grad(v.y); g.z *= gelu_erf_grad(v.z); g.w *= gelu_erf_grad(v.w);
+    V4<T>::st(dx + q * 4, g);
+  }
+}
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+    float4 u = V4<T>::ld(a + q * 4);
+    const float4 v = V4<T>::ld(b + q * 4);
+    u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+    V4<T>::st(y + q * 4, u);
+  }
+}
+
+// ---- optimiser -----------------------------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = *reinterpret_cast<const float4*>(g + q * 4);
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ void adamw_kernel(HeroAdamW a, float bc1, float bc2) {
+  float gs = a.grad_scale;
+  if (a.grad_sumsq) {
+    const float norm = sqrtf(*a.grad_sumsq) * fabsf(a.grad_scale);
+    const float clip = a.max_grad_norm / (norm + 1e-6f);
+    if (clip < 1.f) gs *= clip;
+  }
+  const float step_size = a.lr * sqrtf(bc2) / bc1;
+  const float decay = a.lr * a.weight_decay;
+  bf16_t* sh = static_cast<bf16_t*>(a.shadow);
+  const size_t n4 = a.n >> 2;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+    float4 p = *reinterpret_cast<float4*>(a.p + q * 4);
+    const float4 g4 = *reinterpret_cast<const float4*>(a.g + q * 4);
+    float4 m = *reinterpret_cast<float4*>(a.m + q * 4);
+    float4 v = *reinterpret_cast<float4*>(a.v + q * 4);
+    float* pp = &p.x; const float* gp = &g4.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g = gp[k] * gs;
+      mp[k] = a.beta1 * mp[k] + (1.f - a.beta1) * g;
+      vp[k] = a.beta2 * vp[k] + (1.f - a.beta2) * g * g;
+      pp[k] -= step_size * mp[k] / (sqrtf(vp[k]) + a.eps);
+      pp[k] -= decay * pp[k];
+    }
+    *reinterpret_cast<float4*>(a.p + q * 4) = p;
+    *reinterpret_cast<float4*>(a.m + q * 4) = m;
+    *reinterpret_cast<float4*>(a.v + q * 4) = v;
+    if (sh) V4<bf16_t>::st(sh + q * 4, p);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float g = a.g[i] * gs;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    float p = a.p[i] - step_size * m / (sqrtf(v) + a.eps);
+    p -= decay * p;
+    a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    if (sh) sh[i] = f2bf(p);
+  }
+}
+
+static inline int grid_for(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+}  // namespace hero
+
+using namespace hero;
+
+extern "C" int hero_gather_rows(const void* a, const void* b, const int32_t* idx, void* out, int rows, int cols, int dtype,
+                                hero_stream_t stream) {
+  HERO_REQUIRE(idx && out, "hero_gather_rows: null pointer");
+  HERO_REQUIRE(cols > 0 && cols % 4 == 0, "hero_gather_rows: cols (%d) must be a multiple of 4", cols);
+  if (rows <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((size_t)rows * (cols >> 2));
+  if (dtype == HERO_F32)
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, idx, (float*)out, rows, cols);
+  else if (dtype == HERO_BF16)
+    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, idx, (bf16_t*)out, rows, cols);
+  else { set_error("hero_gather_rows: bad dtype %d", dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_gather_rows");
+}
+
+extern "C" int hero_csr_gather_sum(const void* src, const int32_t* offsets, const int32_t* entries, void* out, int rows,
+                                   int cols, int dtype, hero_stream_t stream) {
+  HERO_REQUIRE(src && offsets && out, "hero_csr_gather_sum: null pointer");
+  HERO_REQUIRE(cols > 0 && cols % 4 == 0, "hero_csr_gather_sum: cols (%d) must be a multiple of 4", cols);
+  if (rows <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((size_t)rows * (cols >> 2));
+  if (dtype == HERO_F32)
+    hipLaunchKernelGGL(csr_gather_sum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, offsets, entries, (float*)out, rows, cols);
+  else if (dtype == HERO_BF16)
+    hipLaunchKernelGGL(csr_gather_sum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)src, offsets, entries, (bf16_t*)out, rows, cols);
+  else { set_error("hero_csr_gather_sum: bad dtype %d", dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_csr_gather_sum");
+}
+
+extern "C" int hero_scatter_add_rows(const void* src, const int32_t* idx, void* dst_a, void* dst_b, int rows, int cols,
+                                     int src_dtype, int dst_dtype, int skip_idx, hero_stream_t stream) {
+  HERO_REQUIRE(src && idx && dst_a, "hero_scatter_add_rows: null pointer");
+  HERO_REQUIRE(cols > 0 && cols % 2 == 0, "hero_scatter_add_rows: cols (%d) must be even", cols);
+  if (rows <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((size_t)rows * (cols >> 1));
+  const int skip = skip_idx >= 0 ? skip_idx : -1;
+  if (src_dtype == HERO_F32 && dst_dtype == HERO_F32)
+    hipLaunchKernelGGL((scatter_add_rows_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, idx, (float*)dst_a, (float*)dst_b, rows, cols, skip);
+  else if (src_dtype == HERO_BF16 && dst_dtype == HERO_F32)
+    hipLaunchKernelGGL((scatter_add_rows_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, idx, (float*)dst_a, (float*)dst_b, rows, cols, skip);
+  else if (src_dtype == HERO_BF16 && dst_dtype == HERO_BF16)
+    hipLaunchKernelGGL((scatter_add_rows_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, idx, (bf16_t*)dst_a, (bf16_t*)dst_b, rows, cols, skip);
+  else { set_error("hero_scatter_add_rows: unsupported dtypes %d -> %d", src_dtype, dst_dtype); return HERO_ERR_UNSUPPORTED; }
+  return check_launch("hero_scatter_add_rows");
+}
+
+extern "C" int hero_cast(const void* src, void* dst, size_t n, int sd, int dd, hero_stream_t stream) {
+  HERO_REQUIRE(src && dst, "hero_cast: null pointer");
+  if (n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(n >> 2);
+  if (sd == HERO_F32 && dd == HERO_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (sd == HERO_BF16 && dd == HERO_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+  else if (sd == HERO_F32 && dd == HERO_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else if (sd == HERO_BF16 && dd == HERO_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+  else { set_error("hero_cast: bad dtypes %d -> %d", sd, dd); return HERO_ERR_ARG; }
+  return check_launch("hero_cast");
+}
+
+extern "C" int hero_relu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, hero_stream_t stream) {
+  HERO_REQUIRE(dy && y && dx, "hero_relu_bwd: null pointer");
+  HERO_REQUIRE(n % 4 == 0, "hero_relu_bwd: n must be a multiple of 4");
+  if (n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(n >> 2);
+  if (dtype == HERO_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)y, (float*)dx, n);
+  else if (dtype == HERO_BF16) hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n);
+  else { set_error("hero_relu_bwd: bad dtype %d", dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_relu_bwd");
+}
+
+extern "C" int hero_gelu_bwd(const void* dy, const void* u, void* dx, size_t n, int dtype, hero_stream_t stream) {
+  HERO_REQUIRE(dy && u && dx, "hero_gelu_bwd: null pointer");
+  HERO_REQUIRE(n % 4 == 0, "hero_gelu_bwd: n must be a multiple of 4");
+  if (n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(n >> 2);
+  if (dtype == HERO_F32) hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)u, (float*)dx, n);
+  else if (dtype == HERO_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)dx, n);
+  else { set_error("hero_gelu_bwd: bad dtype %d", dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_gelu_bwd");
+}
+
+extern "C" int hero_add(const void* a, const void* b, void* y, size_t n, int dtype, hero_stream_t stream) {
+  HERO_REQUIRE(a && b && y, "hero_add: null pointer");
+  HERO_REQUIRE(n % 4 == 0, "hero_add: n must be a multiple of 4");
+  if (n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(n >> 2);
+  if (dtype == HERO_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)y, n);
+  else if (dtype == HERO_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+  else { set_error("hero_add: bad dtype %d", dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_add");
+}
+
+extern "C" int hero_sumsq(const float* g, size_t n, float* sumsq, hero_stream_t stream) {
+  HERO_REQUIRE(g && sumsq, "hero_sumsq: null pointer");
+  if (n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n, sumsq);
+  return check_launch("hero_sumsq");
+}
+
+extern "C" int hero_adamw(const HeroAdamW* a, hero_stream_t stream) {
+  HERO_REQUIRE(a && a->p && a->g && a->m && a->v, "hero_adamw: null pointer");
+  HERO_REQUIRE(a->step >= 1, "hero_adamw: step must be >= 1");
+  if (a->n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float bc1 = 1.f - powf(a->beta1, (float)a->step);
+  const float bc2 = 1.f - powf(a->beta2, (float)a->step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n >> 2)), dim3(256), 0, s, *a, bc1, bc2);
+  return check_launch("hero_adamw");
+}

@@ -1,0 +1,549 @@
+"""Autograd functions over the libhero_hip.so kernels.
+
+Everything arithmetic on the encoder path runs in hand-written HIP kernels reached through the
+C ABI (hero_amd/_lib.py); torch is used here for device memory, stream handles, autograd
+bookkeeping and a few index tensors.  No function in this file has a CPU or torch-eager
+fallback.
+
+Block structure (one autograd node each, residual fan-in fused into GEMM epilogues):
+  attn_block : LN(drop(ctx Wo^T + bo) + x),  ctx = MHA(x Wqkv^T + bqkv)     model/layers.py:217-222
+  ffn_block  : LN(drop(gelu(a W1^T + b1) W2^T + b2) + a)                    model/layers.py:264-272
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+# --------------------------------------------------------------------------------------------- #
+# global switches
+# --------------------------------------------------------------------------------------------- #
+_COMPUTE_DTYPE = torch.bfloat16
+
+
+def set_compute_dtype(dtype):
+    """torch.bfloat16 (default: bf16 storage + bf16 MFMA, fp32 accumulate) or torch.float32
+    (exact-f32 MFMA path used for the parity gate)."""
+    global _COMPUTE_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _COMPUTE_DTYPE = dtype
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+class _Rng:
+    """Counter-based dropout state: one device uint64 seed word per device + a site counter."""
+
+    def __init__(self):
+        self.seeds = {}
+        self.site = 0
+
+    def seed_tensor(self, device):
+        key = (device.type, device.index)
+        t = self.seeds.get(key)
+        if t is None:
+            t = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64,
+                             device=device)
+            self.seeds[key] = t
+        return t
+
+    def make(self, p, training, device):
+        if not training or p <= 0.0:
+            return None
+        if p >= 1.0:
+            raise ValueError("dropout p must be < 1")
+        self.site += 1
+        return L.Dropout(self.seed_tensor(device).data_ptr(), self.site,
+                         max(1, int(round(p * 65536.0))), 1.0 / (1.0 - p))
+
+
+RNG = _Rng()
+
+
+def manual_seed(seed, device=None):
+    """Reset the dropout stream (kept on the device so that hipGraph replays can advance it)."""
+    RNG.site = 0
+    for t in RNG.seeds.values():
+        t.fill_(seed & 0x7FFFFFFFFFFFFFFF)
+    if device is not None:
+        RNG.seed_tensor(torch.device(device)).fill_(seed & 0x7FFFFFFFFFFFFFFF)
+
+
+def advance_seed():
+    """Advance every device seed word by one (a device-side op: safe inside graph capture)."""
+    for t in RNG.seeds.values():
+        t.add_(1)
+
+
+def _d(drop):
+    return drop if drop is not None else L.no_dropout()
+
+
+# --------------------------------------------------------------------------------------------- #
+# compute copies of the fp32 master weights
+# --------------------------------------------------------------------------------------------- #
+_WCACHE = {}
+_WEPOCH = [0]
+
+
+def notify_weights_updated():
+    """Call after parameters were changed in a way autograd's version counters cannot see
+    (raw-pointer optimisers such as hero_amd.optim.AdamW, or `p.data` updates)."""
+    _WEPOCH[0] += 1
+
+
+def clear_weight_cache():
+    _WCACHE.clear()
+
+
+def packed(params, dtype):
+    """Row-concatenate fp32 parameters into one contiguous tensor of `dtype` (cached)."""
+    params = tuple(params)
+    if len(params) == 1 and dtype == torch.float32 and params[0].is_contiguous():
+        return params[0].detach()
+    key = (tuple(id(p) for p in params), dtype)
+    sig = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), _WEPOCH[0])
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    rows = sum(p.shape[0] for p in params)
+    out = hit[1] if hit is not None else torch.empty((rows,) + tuple(params[0].shape[1:]),
+                                                     dtype=dtype, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        dst = out[off:off + p.shape[0]]
+        L.check(L.lib().hero_cast(L.ptr(p.detach().contiguous()), dst.data_ptr(), n, L.F32,
+                                  L.dt(out), L.stream()))
+        off += p.shape[0]
+    _WCACHE[key] = (sig, out)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- #
+# raw kernel wrappers (no autograd)
+# --------------------------------------------------------------------------------------------- #
+def k_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, al, bl, dtype_code, bias=None, residual=None,
+           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None):
+    epi = L.GemmEpilogue(L.ptr(bias), L.ptr(residual), L.ptr(aux), act, 1 if out_f32 else 0,
+                         beta, split_k, _d(drop))
+    L.check(L.lib().hero_gemm(L.ptr(A), L.ptr(B), L.ptr(Cm), M, N, K, lda, ldb, ldc, al, bl,
+                              dtype_code, C.byref(epi), L.stream()))
+
+
+def k_linear(x2, Wc, bias=None, act=L.ACT_NONE, aux=None, residual=None, drop=None):
+    """y[M,N] = epilogue(x2[M,K] @ Wc[N,K]^T)."""
+    M, K = x2.shape
+    N = Wc.shape[0]
+    y = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+    k_gemm(x2, Wc, y, M, N, K, K, K, N, L.LAYOUT_K, L.LAYOUT_K, L.dt(x2), bias=bias,
+           residual=residual, aux=aux, act=act, drop=drop)
+    return y
+
+
+def k_dgrad(dy2, Wc, act=L.ACT_NONE, aux=None, residual=None):
+    """dx[M,K] = epilogue(dy2[M,N] @ Wc[N,K])."""
+    M, N = dy2.shape
+    K = Wc.shape[1]
+    dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+    k_gemm(dy2, Wc, dx, M, K, N, N, K, K, L.LAYOUT_K, L.LAYOUT_O, L.dt(dy2), act=act, aux=aux,
+           residual=residual)
+    return dx
+
+
+def _split_for(n_out, n_in, rows, bk):
+    tiles = ((n_out + 127) // 128) * ((n_in + 127) // 128)
+    split = max(1, min(8, -(-256 // tiles)))
+    ktiles = max(1, -(-rows // bk))
+    return max(1, min(split, ktiles // 4))
+
+
+def k_wgrad(dy2, x2):
+    """dW[N,K] (fp32) = dy2[M,N]^T @ x2[M,K]."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    dW = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    split = _split_for(N, K, M, 64 if dy2.dtype == torch.bfloat16 else 32)
+    k_gemm(dy2, x2, dW, N, K, M, N, K, K, L.LAYOUT_O, L.LAYOUT_O, L.dt(dy2), out_f32=True,
+           beta=0.0, split_k=split)
+    return dW
+
+
+def k_colsum(dy2):
+    M, N = dy2.shape
+    out = torch.empty((N,), dtype=torch.float32, device=dy2.device)
+    ws = torch.empty((256 * N,), dtype=torch.float32, device=dy2.device)
+    L.check(L.lib().hero_colsum(L.ptr(dy2), L.ptr(out), M, N, N, L.dt(dy2), 0.0, L.ptr(ws),
+                                L.stream()))
+    return out
+
+
+def k_ln_fwd(x2, gamma, beta, eps, out_dtype, rows, cols, tabs=(), idxs=(), want_pre=False,
+             drop=None, device=None):
+    device = device or (x2.device if x2 is not None else gamma.device)
+    y = torch.empty((rows, cols), dtype=out_dtype, device=device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=device)
+    pre = torch.empty((rows, cols), dtype=out_dtype, device=device) if want_pre else None
+    a = L.LnFwd()
+    a.x = L.ptr(x2)
+    for k in range(3):
+        a.tab[k] = L.ptr(tabs[k]) if k < len(tabs) else None
+        a.idx[k] = L.ptr(idxs[k]) if k < len(idxs) and idxs[k] is not None else None
+    a.gamma, a.beta, a.y, a.pre = L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(pre)
+    a.mean, a.rstd = L.ptr(mean), L.ptr(rstd)
+    a.rows, a.cols, a.eps = rows, cols, eps
+    a.x_dtype = L.dt(x2) if x2 is not None else L.dt(y)
+    a.y_dtype = L.dt(y)
+    a.dropout = _d(drop)
+    L.check(L.lib().hero_layernorm_fwd(C.byref(a), L.stream()))
+    return y, mean, rstd, pre
+
+
+def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_out=None,
+             drop_in=None):
+    rows, cols = dy2.shape
+    dev = dy2.device
+    dx = torch.empty_like(dy2) if want_dx else None
+    dxd = torch.empty_like(dy2) if (want_dx and drop_in is not None) else None
+    dg = torch.empty((cols,), dtype=torch.float32, device=dev) if want_params else None
+    db = torch.empty((cols,), dtype=torch.float32, device=dev) if want_params else None
+    ws = torch.empty((512 * cols,), dtype=torch.float32, device=dev) if want_params else None
+    a = L.LnBwd()
+    a.x, a.dy, a.gamma, a.mean, a.rstd = L.ptr(x2), L.ptr(dy2), L.ptr(gamma), L.ptr(mean), L.ptr(rstd)
+    a.dx, a.dx_dropped, a.dgamma, a.dbeta = L.ptr(dx), L.ptr(dxd), L.ptr(dg), L.ptr(db)
+    a.grad_beta, a.workspace = 0.0, L.ptr(ws)
+    a.rows, a.cols, a.x_dtype, a.dtype = rows, cols, L.dt(x2), L.dt(dy2)
+    a.dropout_out, a.dropout_in = _d(drop_out), _d(drop_in)
+    L.check(L.lib().hero_layernorm_bwd(C.byref(a), L.stream()))
+    return dx, (dxd if dxd is not None else dx), dg, db
+
+
+def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True):
+    D = H * 64
+    ctx = torch.empty((S * Lq, D), dtype=qkv.dtype, device=qkv.device)
+    probs = torch.empty((S, H, Lq, Lq), dtype=torch.float32, device=qkv.device) if want_probs else None
+    a = L.Attn(L.ptr(qkv), L.ptr(mask_add), L.ptr(ctx), L.ptr(probs), None, None, S, Lq, H,
+               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop))
+    L.check(L.lib().hero_attention_fwd(C.byref(a), L.stream()))
+    return ctx, probs
+
+
+def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None):
+    dqkv = torch.empty_like(qkv)
+    a = L.Attn(L.ptr(qkv), None, None, L.ptr(probs), L.ptr(dctx), L.ptr(dqkv), S, Lq, H,
+               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop))
+    L.check(L.lib().hero_attention_bwd(C.byref(a), L.stream()))
+    return dqkv
+
+
+def k_gather_rows(a, b, idx, rows, cols):
+    ref = a if a is not None else b
+    out = torch.empty((rows, cols), dtype=ref.dtype, device=ref.device)
+    L.check(L.lib().hero_gather_rows(L.ptr(a), L.ptr(b), L.ptr(idx), L.ptr(out), rows, cols,
+                                     L.dt(ref), L.stream()))
+    return out
+
+
+def k_scatter_add(src2, idx, dst_a, dst_b=None, skip=-1):
+    rows, cols = src2.shape
+    L.check(L.lib().hero_scatter_add_rows(L.ptr(src2), L.ptr(idx), L.ptr(dst_a), L.ptr(dst_b), rows,
+                                          cols, L.dt(src2), L.dt(dst_a), skip, L.stream()))
+
+
+def k_cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    L.check(L.lib().hero_cast(L.ptr(x), L.ptr(y), x.numel(), L.dt(x), L.dt(y), L.stream()))
+    return y
+
+
+def k_act_bwd(dy, aux, act):
+    dx = torch.empty_like(dy)
+    fn = L.lib().hero_relu_bwd if act == L.ACT_RELU else L.lib().hero_gelu_bwd
+    L.check(fn(L.ptr(dy), L.ptr(aux), L.ptr(dx), dy.numel(), L.dt(dy), L.stream()))
+    return dx
+
+
+def _as2d(x):
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x.view(-1, x.shape[-1])
+
+
+def as_mask_add(mask, S, Lq):
+    """Reference mask convention -> [S, L] additive fp32.  Accepts the (S,L) 0/1 mask of
+    BertEncoder.forward or the extended (S,1,1,L) additive mask BertLayer receives."""
+    if mask is None:
+        return None
+    if mask.dim() == 4:
+        if mask.shape[1] != 1 or mask.shape[2] != 1:
+            raise NotImplementedError("hero_amd attention supports key masks of shape (S,1,1,L) only")
+        return mask.reshape(S, Lq).to(torch.float32).contiguous()
+    return ((1.0 - mask.reshape(S, Lq).to(torch.float32)) * -10000.0).contiguous()
+
+
+# --------------------------------------------------------------------------------------------- #
+# autograd functions
+# --------------------------------------------------------------------------------------------- #
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return k_cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return k_cast(dy.contiguous(), ctx.src), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) [+ residual]; act in {none, relu, gelu}.  (nn.Linear call sites outside
+    the fused blocks: img_linear, frame_transform, query_input_proj, standalone sub-modules.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, residual):
+        x2 = _as2d(x)
+        Wc = packed((weight,), x2.dtype)
+        aux = torch.empty((x2.shape[0], Wc.shape[0]), dtype=x2.dtype, device=x2.device) \
+            if act != L.ACT_NONE else None
+        r2 = _as2d(residual) if residual is not None else None
+        y = k_linear(x2, Wc, bias.detach() if bias is not None else None, act=act, aux=aux,
+                     residual=r2)
+        ctx.act = act
+        ctx.has_res = residual is not None
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, Wc, aux)
+        ctx.has_bias = bias is not None
+        return y.view(*x.shape[:-1], Wc.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, Wc, aux = ctx.saved_tensors
+        dy2 = _as2d(dy)
+        dz = dy2 if ctx.act == L.ACT_NONE else k_act_bwd(dy2, aux, ctx.act)
+        dx = k_dgrad(dz, Wc).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dW = k_wgrad(dz, x2) if ctx.needs_input_grad[1] else None
+        db = k_colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dres = dy if ctx.has_res else None
+        return dx, dW, db, None, dres
+
+
+def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None):
+    return LinearFn.apply(x, weight, bias, act, residual)
+
+
+class EmbedLnFn(torch.autograd.Function):
+    """y = dropout(LN(x + sum_k table_k[idx_k])) — embedding sums of model/embed.py fused with their
+    LayerNorm.  idx_k None = row 0 of the given (fp32) table slice for every row."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, drop, out_dtype, skip_idx, idxs, *tables):
+        x2 = _as2d(x) if x is not None else None
+        cols = gamma.shape[0]
+        rows = x2.shape[0] if x2 is not None else idxs[0].numel()
+        tabs = [t.detach() for t in tables]
+        y, mean, rstd, pre = k_ln_fwd(x2, gamma.detach(), beta.detach(), eps, out_dtype, rows, cols,
+                                      tabs=tabs, idxs=idxs, want_pre=len(tables) > 0, drop=drop,
+                                      device=gamma.device)
+        ctx.drop, ctx.idxs, ctx.skip = drop, idxs, skip_idx
+        ctx.tab_shapes = [t.shape for t in tables]
+        ctx.has_x = x is not None
+        ctx.xshape = x.shape if x is not None else None
+        ctx.save_for_backward(pre if pre is not None else x2, gamma.detach(), mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pre, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _as2d(dy)
+        want_dx = (ctx.has_x and ctx.needs_input_grad[0]) or len(ctx.tab_shapes) > 0
+        dx, _, dg, db = k_ln_bwd(pre, dy2, gamma, mean, rstd, want_dx=want_dx, drop_out=ctx.drop)
+        grads_t = []
+        for k, shp in enumerate(ctx.tab_shapes):
+            if not ctx.needs_input_grad[8 + k]:
+                grads_t.append(None)
+                continue
+            g = torch.zeros(shp, dtype=torch.float32, device=dy.device)
+            idx = ctx.idxs[k] if k < len(ctx.idxs) else None
+            if idx is None:
+                g.view(-1, shp[-1])[0].copy_(k_colsum(dx))
+            else:
+                k_scatter_add(dx, idx, g, None, ctx.skip[k] if ctx.skip else -1)
+            grads_t.append(g)
+        gx = dx.view(ctx.xshape) if (ctx.has_x and ctx.needs_input_grad[0]) else None
+        return (gx, dg, db, None, None, None, None, None) + tuple(grads_t)
+
+
+def embed_ln(x, gamma, beta, eps, drop, out_dtype, tables=(), idxs=(), skip_idx=None):
+    return EmbedLnFn.apply(x, gamma, beta, eps, drop, out_dtype, skip_idx, tuple(idxs), *tables)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[r] = a[idx[r]] (idx>=0) | 0 (idx==-1) | b[-idx-2]."""
+
+    @staticmethod
+    def forward(ctx, a, b, idx):
+        a2, b2 = _as2d(a), (_as2d(b) if b is not None else None)
+        ctx.save_for_backward(idx)
+        ctx.ashape, ctx.bshape = a.shape, (b.shape if b is not None else None)
+        return k_gather_rows(a2, b2, idx, idx.numel(), a2.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy2 = _as2d(dy)
+        da = torch.zeros(ctx.ashape, dtype=dy.dtype, device=dy.device)
+        db = torch.zeros(ctx.bshape, dtype=dy.dtype, device=dy.device) if ctx.bshape is not None else None
+        k_scatter_add(dy2, idx, da, db)
+        return da, db, None
+
+
+class CsrGatherSumFn(torch.autograd.Function):
+    """out[r] = sum_e src[entries[e]], e in [offsets[r], offsets[r+1]); inverse = src row -> out row
+    (each source row feeds at most one output row: collect_frame_outputs, model/model.py:156-187)."""
+
+    @staticmethod
+    def forward(ctx, src, offsets, entries, inverse, n_out):
+        s2 = _as2d(src)
+        out = torch.empty((n_out, s2.shape[1]), dtype=s2.dtype, device=s2.device)
+        L.check(L.lib().hero_csr_gather_sum(L.ptr(s2), L.ptr(offsets), L.ptr(entries), L.ptr(out),
+                                            n_out, s2.shape[1], L.dt(s2), L.stream()))
+        ctx.save_for_backward(inverse)
+        ctx.sshape = src.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inverse,) = ctx.saved_tensors
+        dy2 = _as2d(dy)
+        ds = k_gather_rows(dy2, None, inverse, inverse.numel(), dy2.shape[1])
+        return ds.view(ctx.sshape), None, None, None, None
+
+
+# ---- transformer blocks ------------------------------------------------------------------------
+def _attn_fwd_core(x2, S, Lq, H, mask_add, Wqkv, bqkv, p_attn_drop):
+    qkv = k_linear(x2, Wqkv, bqkv)
+    ctxt, probs = k_attn_fwd(qkv, mask_add, S, Lq, H, drop=p_attn_drop)
+    return qkv, ctxt, probs
+
+
+class SelfAttentionFn(torch.autograd.Function):
+    """BertSelfAttention (model/layers.py:124-164): ctx = MHA(x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_add, H, drop_p, wq, bq, wk, bk, wv, bv):
+        S, Lq, D = x.shape
+        x2 = _as2d(x)
+        Wqkv = packed((wq, wk, wv), x2.dtype)
+        bqkv = packed((bq, bk, bv), torch.float32)
+        qkv, ctxt, probs = _attn_fwd_core(x2, S, Lq, H, mask_add, Wqkv, bqkv, drop_p)
+        ctx.dims, ctx.drop = (S, Lq, H, D), drop_p
+        ctx.save_for_backward(x2, Wqkv, qkv, probs)
+        return ctxt.view(S, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dctx):
+        x2, Wqkv, qkv, probs = ctx.saved_tensors
+        S, Lq, H, D = ctx.dims
+        dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop)
+        dx = k_dgrad(dqkv, Wqkv).view(S, Lq, D)
+        dW = k_wgrad(dqkv, x2)
+        db = k_colsum(dqkv)
+        return (dx, None, None, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D], dW[2 * D:], db[2 * D:])
+
+
+class ProjResLnFn(torch.autograd.Function):
+    """BertSelfOutput / BertOutput (model/layers.py:175-179, 250-254): LN(drop(h W^T + b) + res)."""
+
+    @staticmethod
+    def forward(ctx, h, res, eps, drop, w, b, gamma, beta):
+        h2, r2 = _as2d(h), _as2d(res)
+        Wc = packed((w,), h2.dtype)
+        y = k_linear(h2, Wc, b.detach(), residual=r2, drop=drop)
+        out, mean, rstd, _ = k_ln_fwd(y, gamma.detach(), beta.detach(), eps, y.dtype, y.shape[0], y.shape[1])
+        ctx.drop = drop
+        ctx.hshape, ctx.rshape = h.shape, res.shape
+        ctx.save_for_backward(h2, Wc, y, mean, rstd, gamma.detach())
+        return out.view(res.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, Wc, y, mean, rstd, gamma = ctx.saved_tensors
+        dy, dyd, dg, dbt = k_ln_bwd(y, _as2d(dout), gamma, mean, rstd, drop_in=ctx.drop)
+        dh = k_dgrad(dyd, Wc).view(ctx.hshape)
+        return dh, dy.view(ctx.rshape), None, None, k_wgrad(dyd, h2), k_colsum(dyd), dg, dbt
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """BertAttention (model/layers.py:217-222) as ONE node: a = LN(drop(MHA(x) Wo^T + bo) + x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_add, H, eps, drop_attn, drop_hid, wq, bq, wk, bk, wv, bv, wo, bo, g1, b1):
+        S, Lq, D = x.shape
+        x2 = _as2d(x)
+        Wqkv = packed((wq, wk, wv), x2.dtype)
+        bqkv = packed((bq, bk, bv), torch.float32)
+        Wo = packed((wo,), x2.dtype)
+        qkv, ctxt, probs = _attn_fwd_core(x2, S, Lq, H, mask_add, Wqkv, bqkv, drop_attn)
+        y1 = k_linear(ctxt, Wo, bo.detach(), residual=x2, drop=drop_hid)
+        a, mean, rstd, _ = k_ln_fwd(y1, g1.detach(), b1.detach(), eps, y1.dtype, S * Lq, D)
+        ctx.dims, ctx.drops = (S, Lq, H, D), (drop_attn, drop_hid)
+        ctx.save_for_backward(x2, Wqkv, Wo, qkv, probs, ctxt, y1, mean, rstd, g1.detach())
+        return a.view(S, Lq, D)
+
+    @staticmethod
+    def backward(ctx, da):
+        x2, Wqkv, Wo, qkv, probs, ctxt, y1, mean, rstd, g1 = ctx.saved_tensors
+        S, Lq, H, D = ctx.dims
+        drop_attn, drop_hid = ctx.drops
+        dy1, dy1d, dg1, db1 = k_ln_bwd(y1, _as2d(da), g1, mean, rstd, drop_in=drop_hid)
+        dbo = k_colsum(dy1d)
+        dWo = k_wgrad(dy1d, ctxt)
+        dctx = k_dgrad(dy1d, Wo)
+        dqkv = k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=drop_attn)
+        dW = k_wgrad(dqkv, x2)
+        db = k_colsum(dqkv)
+        dx = k_dgrad(dqkv, Wqkv, residual=dy1).view(S, Lq, D)      # + residual-path gradient, fused
+        return (dx, None, None, None, None, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D],
+                dW[2 * D:], db[2 * D:], dWo, dbo, dg1, db1)
+
+
+class FfnBlockFn(torch.autograd.Function):
+    """BertIntermediate + BertOutput (model/layers.py:236-254) as ONE node:
+    out = LN(drop(gelu(a W1^T + b1) W2^T + b2) + a)."""
+
+    @staticmethod
+    def forward(ctx, a, eps, drop_hid, w1, b1, w2, b2, g2, bt2):
+        shp = a.shape
+        a2 = _as2d(a)
+        W1, W2 = packed((w1,), a2.dtype), packed((w2,), a2.dtype)
+        u = torch.empty((a2.shape[0], W1.shape[0]), dtype=a2.dtype, device=a2.device)
+        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU, aux=u)
+        y2 = k_linear(hg, W2, b2.detach(), residual=a2, drop=drop_hid)
+        out, mean, rstd, _ = k_ln_fwd(y2, g2.detach(), bt2.detach(), eps, y2.dtype, y2.shape[0], y2.shape[1])
+        ctx.drop, ctx.shp = drop_hid, shp
+        ctx.save_for_backward(a2, W1, W2, u, hg, y2, mean, rstd, g2.detach())
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, W1, W2, u, hg, y2, mean, rstd, g2 = ctx.saved_tensors
+        dy2, dy2d, dg2, dbt2 = k_ln_bwd(y2, _as2d(dout), g2, mean, rstd, drop_in=ctx.drop)
+        db2 = k_colsum(dy2d)
+        dW2 = k_wgrad(dy2d, hg)
+        du = k_dgrad(dy2d, W2, act=L.ACT_GELU_BWD, aux=u)           # * gelu'(u), fused
+        db1 = k_colsum(du)
+        dW1 = k_wgrad(du, a2)
+        da = k_dgrad(du, W1, residual=dy2).view(ctx.shp)            # + residual-path gradient, fused
+        return da, None, None, dW1, db1, dW2, db2, dg2, dbt2

@@ -1,0 +1,250 @@
+"""Encoders with the reference's public surface (model/encoder.py): RobertaModelConfig,
+RobertaPreTrainedModel, CrossModalTrm, TemporalTrm, QueryFeatEncoder."""
+import copy
+import json
+from collections import defaultdict
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import functional as HF
+from .embed import FrameEmbeddings, ImageEmbeddings, QueryFeatEmbeddings, SubEmbeddings
+from .layers import (BertAttention, BertEncoder, BertLMPredictionHead, BertPooler, LayerNorm,
+                     LinearLayer)
+from .modeling_utils import load_pretrained_weight, mask_logits, pad_tensor_to_mul
+
+_DEFAULTS = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1,
+                 attention_probs_dropout_prob=0.1, max_position_embeddings=512, type_vocab_size=2,
+                 initializer_range=0.02, layer_norm_eps=1e-12, output_attentions=False,
+                 output_hidden_states=False)
+
+
+class RobertaModelConfig(object):
+    """Attribute bag with the reference's constructor forms (model/encoder.py:39-136): an int
+    vocabulary size (+ keyword overrides) or a path to a JSON file."""
+
+    def __init__(self, vocab_size_or_config_json_file, **kwargs):
+        if isinstance(vocab_size_or_config_json_file, str):
+            with open(vocab_size_or_config_json_file, "r", encoding="utf-8") as f:
+                self.__dict__.update(json.load(f))
+        elif isinstance(vocab_size_or_config_json_file, int):
+            self.vocab_size = vocab_size_or_config_json_file
+            for k, v in _DEFAULTS.items():
+                setattr(self, k, kwargs.pop(k, v))
+        else:
+            raise ValueError("First argument must be either a vocabulary size (int) or the path to "
+                             "a pretrained model config file (str)")
+
+    @classmethod
+    def from_dict(cls, json_object):
+        cfg = cls(-1)                       # defaults (incl. layer_norm_eps = 1e-12), then overrides
+        cfg.__dict__.update(json_object)
+        return cfg
+
+    @classmethod
+    def from_json_file(cls, json_file):
+        with open(json_file, "r", encoding="utf-8") as f:
+            return cls.from_dict(json.load(f))
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def to_json_string(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+    __repr__ = to_json_string
+
+
+class RobertaPreTrainedModel(nn.Module):
+    """Weight init + from_pretrained (model/encoder.py:139-201)."""
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        if not isinstance(config, RobertaModelConfig):
+            raise ValueError("Parameter config in `%s(config)` should be an instance of class "
+                             "`RobertaModelConfig`." % self.__class__.__name__)
+        self.config = config
+
+    def init_weights(self, module):
+        """N(0, initializer_range) for Linear/Embedding weights (padding rows included, as in the
+        reference), LayerNorm = (1, 0), Linear bias = 0."""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    @classmethod
+    def load_config(cls, config):
+        return RobertaModelConfig.from_json_file(config) if isinstance(config, str) else config
+
+    @classmethod
+    def from_pretrained(cls, config_file, state_dict, *inputs, **kwargs):
+        model = cls(cls.load_config(config_file), *inputs, **kwargs)
+        return load_pretrained_weight(model, state_dict)
+
+
+class CrossModalTrm(RobertaPreTrainedModel):
+    """Joint frame+subtitle encoder (model/encoder.py:204-389)."""
+
+    def __init__(self, config, vfeat_dim, max_img_seq_len):
+        super().__init__(config)
+        self.encoder = BertEncoder(config)
+        self.embeddings = SubEmbeddings(config)
+        self.img_embeddings = ImageEmbeddings(config, vfeat_dim, max_img_seq_len)
+        self.pooler = BertPooler(config)
+        self.apply(self.init_weights)
+        self.config = config
+        self.lm_head = BertLMPredictionHead(config, self.embeddings.word_embeddings.weight)
+        self.vocab_pad = 0
+        self.register_buffer("pad", torch.zeros(8, config.hidden_size))
+        self.run_pooler = False      # the pooled output is discarded by every 'repr'/'txt' caller
+
+    def pad_vocab(self):
+        emb, n_pad = pad_tensor_to_mul(self.embeddings.word_embeddings.weight.data)
+        emb = nn.Parameter(emb)
+        bias, _ = pad_tensor_to_mul(self.lm_head.bias.data)
+        self.embeddings.word_embeddings.weight = emb
+        self.lm_head.decoder.weight = emb
+        self.lm_head.bias = nn.Parameter(bias)
+        self.vocab_pad = n_pad
+
+    def _type_row(self):
+        return self.embeddings.token_type_embeddings.weight[1:2]
+
+    def _compute_txt_embeddings(self, input_ids, position_ids, txt_type_ids=None):
+        return self.embeddings(input_ids=input_ids, position_ids=position_ids,
+                               token_type_ids=txt_type_ids)
+
+    def _compute_img_embeddings(self, img_feat, img_pos_ids, img_type_ids=None, img_masks=None):
+        if img_type_ids is not None:
+            raise NotImplementedError("img_type_ids is always None in HERO (type row 1 is used)")
+        return self.img_embeddings(img_feat, self._type_row(), img_pos_ids, img_masks)
+
+    @staticmethod
+    def _flat_gather_index(gather_index, max_vl, max_sl):
+        """reference index into cat([img, txt], dim=1) -> flat row index for hero_gather_rows
+        (>= 0: img row, <= -2: txt row)."""
+        T = gather_index.shape[0]
+        row = torch.arange(T, device=gather_index.device).unsqueeze(1)
+        g = gather_index.to(torch.int64)
+        flat = torch.where(g < max_vl, row * max_vl + g, -(row * max_sl + (g - max_vl)) - 2)
+        return flat.reshape(-1).to(torch.int32).contiguous()
+
+    def _compute_img_txt_embeddings(self, input_ids, position_ids, img_feat, img_pos_ids,
+                                    gather_index, txt_type_ids=None, img_type_ids=None,
+                                    img_masks=None):
+        txt_emb = img_emb = None
+        if input_ids is not None:
+            txt_emb = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
+        if img_feat is not None:
+            img_emb = self._compute_img_embeddings(img_feat, img_pos_ids, img_type_ids, img_masks)
+        if txt_emb is not None and img_emb is not None:
+            assert gather_index is not None
+            T, Lout = gather_index.shape
+            flat = self._flat_gather_index(gather_index, img_emb.shape[1], txt_emb.shape[1])
+            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat)
+            return out.view(T, Lout, -1)
+        if txt_emb is not None:
+            return txt_emb
+        if img_emb is not None:
+            return img_emb
+        raise ValueError("Both img_feat and input_dis are None")
+
+    def init_type_embedding(self):
+        new_emb = nn.Embedding(2, self.config.hidden_size)
+        new_emb.apply(self.init_weights)
+        row0 = self.embeddings.token_type_embeddings.weight.data[0]
+        new_emb.weight.data[0].copy_(row0)
+        new_emb.weight.data[1].copy_(row0)
+        self.embeddings.token_type_embeddings = new_emb.to(row0.device)
+
+    def forward(self, batch, task="repr", compute_loss=True):
+        batch = defaultdict(lambda: None, batch)
+        if task == "repr":
+            return self.forward_repr(batch["f_sub_input_ids"], batch["f_sub_pos_ids"],
+                                     batch["f_v_feats"], batch["f_v_pos_ids"],
+                                     batch["f_attn_masks"], batch["f_gather_index"],
+                                     img_masks=batch["f_v_masks"])
+        if task == "txt":
+            return self.forward_repr(input_ids=batch["input_ids"], position_ids=batch["pos_ids"],
+                                     img_feat=None, img_pos_ids=None,
+                                     attention_mask=batch["attn_masks"], gather_index=None)
+        if task.startswith("mlm"):
+            return self.forward_mlm(batch["input_ids"], batch["position_ids"], batch["v_feat"],
+                                    batch["f_pos_ids"], batch["attn_masks"], batch["gather_index"],
+                                    batch["txt_mask_tgt"], batch["txt_labels"], compute_loss)
+        raise ValueError(f"Unrecognized task {task}")
+
+    def forward_repr(self, input_ids, position_ids, img_feat, img_pos_ids, attention_mask,
+                     gather_index=None, txt_type_ids=None, img_type_ids=None, img_masks=None):
+        emb = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_ids,
+                                               gather_index, txt_type_ids, img_type_ids, img_masks)
+        seq = self.encoder(emb, attention_mask)[0]
+        pooled = self.pooler(seq) if self.run_pooler else None
+        return (seq, pooled)
+
+    def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_ids, attention_mask,
+                    gather_index, txt_mask_tgt, txt_labels=None, compute_loss=True):
+        emb = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_ids,
+                                               gather_index)
+        seq = self.encoder(emb, attention_mask)[0]
+        rows = torch.nonzero(txt_mask_tgt.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32)
+        masked = HF.GatherRowsFn.apply(seq.reshape(-1, seq.shape[-1]), None, rows.contiguous())
+        scores = self.lm_head(masked)
+        if self.vocab_pad:
+            scores = scores[:, :-self.vocab_pad]
+        if compute_loss:
+            return F.cross_entropy(scores, txt_labels, reduction="none")
+        return scores
+
+
+class TemporalTrm(RobertaPreTrainedModel):
+    """Cross-frame encoder over the temporal axis (model/encoder.py:392-423)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.embeddings = FrameEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.pooler = BertPooler(config)
+        self.apply(self.init_weights)
+
+    def forward_encoder(self, embedding_output, attention_mask, pool=False):
+        seq = self.encoder(embedding_output, attention_mask)[0]
+        return self.pooler(seq) if pool else seq
+
+    def forward(self, clip_level_frame_feat, clip_level_pos_ids, attention_mask):
+        emb = self.embeddings(clip_level_frame_feat, position_ids=clip_level_pos_ids)
+        return self.forward_encoder(emb, attention_mask)
+
+
+class QueryFeatEncoder(nn.Module):
+    """Query pooling head (model/encoder.py:426-485): LinearLayer -> pos-emb LN -> one
+    BertAttention (HIP) -> masked softmax pooling (small torch ops on (N, L) scalars)."""
+
+    def __init__(self, config, qfeat_dim, modularized=True):
+        super().__init__()
+        self.query_input_proj = LinearLayer(qfeat_dim, config.hidden_size, layer_norm=True,
+                                            dropout=config.hidden_dropout_prob, relu=True)
+        self.query_pos_embed = QueryFeatEmbeddings(config)
+        self.query_self_attention = BertAttention(config)
+        self.modularized = modularized
+        if modularized:
+            self.modular_vector_mapping = nn.Linear(config.hidden_size, 1, bias=False)
+
+    def get_modularized_queries(self, query, query_mask, return_modular_att=False):
+        scores = self.modular_vector_mapping(query)                               # (N, L, 1)
+        att = F.softmax(mask_logits(scores, query_mask.unsqueeze(2)), dim=1)
+        pooled = torch.einsum("blm,bld->bmd", att, query)[:, 0]
+        return (pooled, att) if return_modular_att else pooled
+
+    def forward(self, query_feat, query_attn_mask, query_pos_ids=None):
+        h = self.query_pos_embed(self.query_input_proj(query_feat), query_pos_ids)
+        m = query_attn_mask.to(torch.float32)
+        ext = ((1.0 - m) * -10000.0)[:, None, None, :]
+        attended = HF.cast(self.query_self_attention(h, ext)[0], torch.float32)
+        return self.get_modularized_queries(attended, m) if self.modularized else attended

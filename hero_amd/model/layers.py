@@ -1,0 +1,242 @@
+"""Transformer building blocks with the reference's module / parameter names
+(linjieli222/HERO model/layers.py) whose forwards run on the libhero_hip.so kernels.
+
+State-dict keys are identical to the reference (separate query/key/value Linear parameters,
+`LayerNorm.weight/bias`, `dense.weight/bias`, `net.1.weight`), so its checkpoints load unchanged.
+`nn.Dropout` children are kept as configuration holders (utils/misc.py:set_dropout rewrites `.p`);
+the dropout itself is applied inside the HIP kernels by a counter-based RNG.
+"""
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import functional as HF
+
+
+class LayerNorm(nn.Module):
+    """Parameter holder + standalone forward for apex FusedLayerNorm call sites."""
+
+    def __init__(self, size, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(size))
+        self.bias = nn.Parameter(torch.zeros(size))
+        self.eps = eps
+        self.normalized_shape = (size,)
+
+    def forward(self, x, dropout=None, out_dtype=None):
+        shp = x.shape
+        y = HF.embed_ln(x, self.weight, self.bias, self.eps, dropout,
+                        out_dtype or (x.dtype if x.dtype == torch.bfloat16 else HF.compute_dtype()))
+        return y.view(shp)
+
+
+BertLayerNorm = LayerNorm
+
+
+def _drop(mod, device):
+    return HF.RNG.make(mod.p, mod.training, device)
+
+
+class GELU(nn.Module):
+    """model/layers.py:64-67 — only ever used right behind an nn.Linear; see MLPLayer/regression
+    heads, which fuse it into that Linear's epilogue."""
+
+    def forward(self, x):  # pragma: no cover - kept for API parity
+        raise RuntimeError("hero_amd: GELU is fused into the preceding Linear (use linear_gelu)")
+
+
+class LinearLayer(nn.Module):
+    """LN -> Dropout -> Linear -> ReLU (model/layers.py:70-93); optional fused residual."""
+
+    def __init__(self, in_hsz, out_hsz, layer_norm=True, dropout=0.1, relu=True):
+        super().__init__()
+        self.relu = relu
+        self.layer_norm = layer_norm
+        if layer_norm:
+            self.LayerNorm = LayerNorm(in_hsz, eps=1e-5)
+        self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
+
+    def forward(self, x, residual=None):
+        cd = HF.compute_dtype()
+        if self.layer_norm:
+            x = self.LayerNorm(x, dropout=_drop(self.net[0], x.device), out_dtype=cd)
+        else:
+            if self.net[0].training and self.net[0].p > 0:
+                raise NotImplementedError("LinearLayer(layer_norm=False) with dropout")
+            x = HF.cast(x, cd)
+        lin = self.net[1]
+        if residual is not None:
+            residual = HF.cast(residual, cd)
+        return HF.linear(x, lin.weight, lin.bias, act=L.ACT_RELU if self.relu else L.ACT_NONE,
+                         residual=residual)
+
+
+class MLPLayer(nn.Module):
+    """model/layers.py:48-61: Linear -> gelu -> LN -> Linear."""
+
+    def __init__(self, in_hsz, out_hsz):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_hsz, in_hsz * 2)
+        self.LayerNorm = LayerNorm(in_hsz * 2, eps=1e-5)
+        self.linear_2 = nn.Linear(in_hsz * 2, out_hsz)
+
+    def forward(self, x):
+        x = HF.cast(x, HF.compute_dtype())
+        h = HF.linear(x, self.linear_1.weight, self.linear_1.bias, act=L.ACT_GELU)
+        h = self.LayerNorm(h)
+        return HF.linear(h, self.linear_2.weight, self.linear_2.bias)
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention "
+                             "heads (%d)" % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        if self.attention_head_size != 64:
+            raise ValueError("hero_amd attention kernels are specialised for head size 64 "
+                             "(HERO-base); got %d" % self.attention_head_size)
+        self.all_head_size = config.hidden_size
+        self.output_attentions = getattr(config, "output_attentions", False)
+        if self.output_attentions:
+            raise NotImplementedError("output_attentions is not supported by the fused attention")
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def qkv_params(self):
+        return (self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                self.value.weight, self.value.bias)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is always None in HERO (model/layers.py:311)")
+        x = HF.cast(hidden_states, HF.compute_dtype())
+        S, Lq, _ = x.shape
+        m = HF.as_mask_add(attention_mask, S, Lq)
+        return (HF.SelfAttentionFn.apply(x, m, self.num_attention_heads,
+                                         _drop(self.dropout, x.device), *self.qkv_params()),)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        return HF.ProjResLnFn.apply(hidden_states, input_tensor, self.LayerNorm.eps,
+                                    _drop(self.dropout, hidden_states.device), self.dense.weight,
+                                    self.dense.bias, self.LayerNorm.weight, self.LayerNorm.bias)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, input_tensor, attention_mask=None, head_mask=None):
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is always None in HERO")
+        x = HF.cast(input_tensor, HF.compute_dtype())
+        S, Lq, _ = x.shape
+        m = HF.as_mask_add(attention_mask, S, Lq)
+        so, o = self.self, self.output
+        a = HF.AttnBlockFn.apply(
+            x, m, so.num_attention_heads, o.LayerNorm.eps, _drop(so.dropout, x.device),
+            _drop(o.dropout, x.device), *so.qkv_params(), o.dense.weight, o.dense.bias,
+            o.LayerNorm.weight, o.LayerNorm.bias)
+        return (a,)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_act != "gelu":
+            raise NotImplementedError("hero_amd implements the erf GELU HERO uses (hidden_act='gelu')")
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+    def forward(self, hidden_states):
+        return HF.linear(hidden_states, self.dense.weight, self.dense.bias, act=L.ACT_GELU)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    forward = BertSelfOutput.forward
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        a = self.attention(hidden_states, attention_mask, head_mask)[0]
+        o = self.output
+        out = HF.FfnBlockFn.apply(a, o.LayerNorm.eps, _drop(o.dropout, a.device),
+                                  self.intermediate.dense.weight, self.intermediate.dense.bias,
+                                  o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias)
+        return (out,)
+
+
+class BertPooler(nn.Module):
+    """model/layers.py:275-287.  Dead value on the 'repr'/'txt' paths (its output is discarded by
+    every caller), so the encoders do not run it unless asked; kept for state-dict parity."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+    def forward(self, hidden_states):
+        first = hidden_states[:, 0].contiguous()
+        return self.activation(HF.cast(HF.linear(first, self.dense.weight, self.dense.bias),
+                                       torch.float32))
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if getattr(config, "output_attentions", False) or getattr(config, "output_hidden_states", False):
+            raise NotImplementedError("output_attentions / output_hidden_states are off in HERO")
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        x = HF.cast(hidden_states, HF.compute_dtype())
+        S, Lq, _ = x.shape
+        m = HF.as_mask_add(attention_mask, S, Lq)        # (1-m)*-10000, model/layers.py:299-302
+        m4 = m.view(S, 1, 1, Lq) if m is not None else None
+        for layer in self.layer:
+            x = layer(x, m4, None)[0]
+        return (x,)
+
+
+class BertLMPredictionHead(nn.Module):
+    """model/layers.py:330-354; decoder weight tied to the word embedding."""
+
+    def __init__(self, config, bert_model_embedding_weights):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=1e-5)
+        self.decoder = nn.Linear(bert_model_embedding_weights.size(1),
+                                 bert_model_embedding_weights.size(0), bias=False)
+        self.decoder.weight = bert_model_embedding_weights
+        self.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
+
+    def forward(self, hidden_states):
+        x = HF.cast(hidden_states, HF.compute_dtype())
+        h = HF.linear(x, self.dense.weight, self.dense.bias, act=L.ACT_GELU)
+        h = self.LayerNorm(h)
+        return HF.cast(HF.linear(h, self.decoder.weight, self.bias), torch.float32)

@@ -1,0 +1,124 @@
+"""Synthetic batches with the exact keys / shapes / dtypes of the reference's collate functions
+(data/data.py:406-471 video_collate, data/vcmr.py:120-145 query_collate), SURVEY.md §8(d).
+
+Nothing here reads a dataset: features ~ N(0,1), token ids uniform in [3, vocab) with SEP (2) first
+for subtitles and CLS (0) first for queries, pad id 1, masks = length prefixes.
+"""
+import torch
+
+# name -> (videos, frames/video, subs/video, frames/sub, tokens/sub, query tokens)
+SHAPES = {
+    "D1": dict(videos=2, frames=32, subs=8, fps=4, toks=8, qtoks=12),       # config 1 (plumbing)
+    "D2": dict(videos=32, frames=60, subs=15, fps=4, toks=20, qtoks=15),    # TVR finetune, per GPU
+    "D4": dict(videos=512, frames=256, subs=64, fps=4, toks=20, qtoks=15),  # long-video stress
+}
+
+
+def gather_index(txt_lens, v_lens, max_vl, out_size):
+    """data/data.py:504-512."""
+    n = len(txt_lens)
+    gi = torch.arange(out_size, dtype=torch.long).unsqueeze(0).repeat(n, 1)
+    for i, (tl, nf) in enumerate(zip(txt_lens, v_lens)):
+        gi[i, nf:nf + tl] = torch.arange(max_vl, max_vl + tl)
+    return gi
+
+
+def video_batch(subs, n_frames, vfeat_dim, vocab, gen, max_frames=None):
+    """subs: per video a list of (frame index list, n_tokens incl. SEP)."""
+    rows_v, rows_t = [], []
+    for vs in subs:
+        for fr, nt in vs:
+            rows_v.append(max(len(fr), 1))
+            rows_t.append(nt)
+    T, max_vl, max_sl = len(rows_v), max(rows_v), max(rows_t)
+    B, max_f = len(subs), max_frames or max(n_frames)
+    c_v = torch.zeros(B, max_f, vfeat_dim)
+    c_m = torch.zeros(B, max_f, dtype=torch.long)
+    for b, nf in enumerate(n_frames):
+        c_v[b, :nf] = torch.randn(nf, vfeat_dim, generator=gen)
+        c_m[b, :nf] = 1
+    ids = torch.ones(T, max_sl, dtype=torch.long)
+    f_v = torch.zeros(T, max_vl, vfeat_dim)
+    f_m = torch.zeros(T, max_vl + max_sl, dtype=torch.long)
+    sub2frm, num_subs, r = [], [], 0
+    for b, vs in enumerate(subs):
+        cur = []
+        for sid, (fr, nt) in enumerate(vs):
+            ids[r, 0] = 2
+            if nt > 1:
+                ids[r, 1:nt] = torch.randint(3, vocab, (nt - 1,), generator=gen)
+            if len(fr):
+                f_v[r, :len(fr)] = c_v[b, fr]
+                f_m[r, :len(fr) + nt] = 1
+            else:                                   # data/data.py:380-382
+                f_m[r, 1:1 + nt] = 1
+            cur.append((sid, list(fr)))
+            r += 1
+        sub2frm.append(cur)
+        num_subs.append(len(vs))
+    return {
+        "f_sub_input_ids": ids,
+        "f_sub_pos_ids": torch.arange(max_sl).clamp(max=511).unsqueeze(0),
+        "f_v_feats": f_v,
+        "f_v_pos_ids": torch.arange(max_vl).unsqueeze(0),
+        "f_attn_masks": f_m,
+        "f_gather_index": gather_index(rows_t, rows_v, max_vl, max_vl + max_sl),
+        "c_v_feats": c_v,
+        "c_attn_masks": c_m,
+        "num_subs": num_subs,
+        "sub_idx2frame_idx": sub2frm,
+    }
+
+
+def query_batch(n, lens, vocab, gen):
+    Lq = max(lens)
+    ids = torch.ones(n, Lq, dtype=torch.long)
+    m = torch.zeros(n, Lq, dtype=torch.long)
+    for i, l in enumerate(lens):
+        ids[i, 0] = 0
+        if l > 1:
+            ids[i, 1:l] = torch.randint(3, vocab, (l - 1,), generator=gen)
+        m[i, :l] = 1
+    return {"query_input_ids": ids, "query_pos_ids": torch.arange(Lq).unsqueeze(0),
+            "query_attn_masks": m}
+
+
+def to_device(batch, device):
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def make_batch(name="D2", vfeat_dim=4352, vocab=50272, seed=1, device="cpu", ragged=False,
+               videos=None):
+    """Canonical (or ragged) TVR-shaped VCMR batch: one query per video (sampled_by_q=True)."""
+    sh = dict(SHAPES[name])
+    if videos is not None:
+        sh["videos"] = videos
+    gen = torch.Generator().manual_seed(seed)
+    B = sh["videos"]
+    if not ragged:
+        subs = [[(list(range(s * sh["fps"], (s + 1) * sh["fps"])), sh["toks"])
+                 for s in range(sh["subs"])] for _ in range(B)]
+        n_frames = [sh["frames"]] * B
+        qlens = [sh["qtoks"]] * B
+    else:
+        subs, n_frames, qlens = [], [], []
+        ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))  # noqa: E731
+        for _ in range(B):
+            nf = ri(30, 100)
+            cur, f0 = [], 0
+            for _s in range(ri(8, 25)):
+                k = ri(0, 8)
+                fr = [f for f in range(f0, min(f0 + k, nf))]
+                f0 += len(fr)
+                cur.append((fr, ri(4, 40)))
+            subs.append(cur)
+            n_frames.append(nf)
+            qlens.append(ri(5, 25))
+    batch = video_batch(subs, n_frames, vfeat_dim, vocab, gen)
+    batch.update(query_batch(B, qlens, vocab, gen))
+    st = torch.tensor([int(torch.randint(0, max(nf - 1, 1), (1,), generator=gen)) for nf in n_frames])
+    ed = torch.minimum(st + 1 + torch.randint(0, 4, (B,), generator=gen),
+                       torch.tensor(n_frames) - 1)
+    batch["targets"] = torch.stack([st, ed], dim=1)
+    batch["q_vidx"] = torch.arange(B)
+    return to_device(batch, device)

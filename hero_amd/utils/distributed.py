@@ -1,0 +1,228 @@
+"""Data-parallel collectives over torch.distributed (backend "nccl" == RCCL over xGMI on ROCm,
+"gloo" in the CPU tests) replacing the reference's Horovod calls (utils/distributed.py,
+model/pretrain.py:427-451).
+
+One process per GPU.  Semantics kept from the reference:
+  * gradient all-reduce is an AVERAGE over ranks (Horovod's allreduce_ default) followed by a
+    division by `rescale_denom`; it happens once per optimiser step, before clipping;
+  * the cross-GPU negative gather has NO collective in its backward: every rank computes the
+    same global loss and gradients are averaged afterwards, so each rank keeps its own slice.
+MI355X-first additions: GradArena keeps all gradients in ONE flat fp32 buffer that autograd
+accumulates into in place, so buckets are all-reduced straight out of it (no flatten/unflatten
+copies) and are launched from autograd hooks while the rest of backward is still running.
+"""
+import pickle
+
+import torch
+import torch.distributed as dist
+
+
+def _on():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if _on() else 1
+
+
+def rank():
+    return dist.get_rank() if _on() else 0
+
+
+# ---- gradient averaging (utils/distributed.py:19-46) -----------------------------------------
+def all_reduce_and_rescale_tensors(tensors, rescale_denom):
+    """Flatten -> ONE all-reduce -> average -> / rescale_denom -> unflatten (in place)."""
+    tensors = list(tensors)
+    if not tensors:
+        return
+    n = world_size()
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    if n > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / (n * float(rescale_denom)))
+    off = 0
+    for t in tensors:
+        k = t.numel()
+        t.copy_(flat[off:off + k].view_as(t))
+        off += k
+
+
+def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
+    """Bucketed broadcast of parameters from `root_rank` (utils/distributed.py:103-151)."""
+    if world_size() == 1:
+        return
+    bucket, filled = [], 0
+
+    def flush():
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.broadcast(flat, src=root_rank)
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+    for t in tensors:
+        sz = t.numel() * t.element_size()
+        if sz > buffer_size:
+            dist.broadcast(t, src=root_rank)
+            continue
+        if filled + sz > buffer_size:
+            flush()
+            bucket, filled = [], 0
+        bucket.append(t)
+        filled += sz
+    flush()
+
+
+class GradArena:
+    """Flat fp32 gradient arena with bucketed, backward-overlapped all-reduce.
+
+    `p.grad` of every parameter is a view into one buffer; autograd accumulates into it in
+    place.  Buckets are cut in reverse parameter order (~ the order gradients become final) and a
+    bucket's all-reduce is issued asynchronously the moment its last gradient has been
+    accumulated (post-accumulate-grad hooks); `finish()` issues the leftovers and waits.
+    The 1/world_size factor is NOT applied here: hand `grad_scale = 1/world_size` to the fused
+    optimiser (hero_amd.optim.AdamW) or call `scale_()`.
+    """
+
+    def __init__(self, params, bucket_bytes=64 << 20, overlap=True):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slices = {}
+        self.buckets = []            # [start, end, n_params]
+        self.bucket_of = {}
+        off, start, count = 0, 0, 0
+        for p in reversed(self.params):
+            n = p.numel()
+            self.slices[p] = (off, off + n)
+            p.grad = self.flat[off:off + n].view_as(p)
+            self.bucket_of[p] = len(self.buckets)
+            off += n
+            count += 1
+            if (off - start) * 4 >= bucket_bytes:
+                self.buckets.append([start, off, count])
+                start, count = off, 0
+        if count:
+            self.buckets.append([start, off, count])
+        self.sync = True
+        self.overlap = overlap
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self.touched = set()
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        self.touched.add(p)
+        if p.grad.data_ptr() != self.flat.data_ptr() + self.slices[p][0] * 4:
+            # something replaced .grad (e.g. zero_grad(set_to_none=True)); fold it back
+            s, e = self.slices[p]
+            self.flat[s:e].add_(p.grad.reshape(-1))
+            p.grad = self.flat[s:e].view_as(p)
+        if not (self.sync and self.overlap) or world_size() == 1:
+            return
+        b = self.bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        s, e, _ = self.buckets[b]
+        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def set_sync(self, flag):
+        """False on gradient-accumulation micro-steps that do not end in an optimiser step."""
+        self.sync = flag
+
+    def finish(self):
+        """Issue all-reduces for buckets the hooks did not complete, then wait for everything."""
+        if world_size() > 1 and self.sync:
+            for b in range(len(self.buckets)):
+                self._launch(b)
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+    def scale_(self, factor):
+        self.flat.mul_(factor)
+
+    def zero(self):
+        self.flat.zero_()
+        self.touched.clear()
+        for p in self.params:                       # re-attach after a foreign zero_grad()
+            if p.grad is None:
+                s, e = self.slices[p]
+                p.grad = self.flat[s:e].view_as(p)
+
+
+# ---- cross-GPU negatives (model/pretrain.py:383-401, 427-451) ---------------------------------
+class _AllGatherRows(torch.autograd.Function):
+    """Variable-dim-0 all-gather; backward = this rank's slice of the gradient, no collective."""
+
+    @staticmethod
+    def forward(ctx, tensor, dims):
+        r, n = rank(), world_size()
+        mx = max(dims)
+        buf = tensor.new_zeros((mx,) + tuple(tensor.shape[1:]))
+        buf[:tensor.shape[0]] = tensor
+        out = [torch.empty_like(buf) for _ in range(n)]
+        dist.all_gather(out, buf.contiguous())
+        ctx.offset, ctx.dim = sum(dims[:r]), tensor.shape[0]
+        return torch.cat([o[:d] for o, d in zip(out, dims)], dim=0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad.narrow(0, ctx.offset, ctx.dim), None
+
+
+def gather_negatives(query, context, context_mask):
+    """All-gather (queries, L2-normalised contexts, masks) across ranks, padding contexts to the
+    global max clip length.  ONE small integer all-gather carries every size needed."""
+    n = world_size()
+    meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]],
+                        dtype=torch.int64, device=query.device)
+    metas = [torch.empty_like(meta) for _ in range(n)]
+    dist.all_gather(metas, meta)
+    metas = torch.stack(metas).tolist()
+    nq = [m[0] for m in metas]
+    nv = [m[1] for m in metas]
+    max_len = max(m[2] for m in metas)
+    pad = max_len - context.shape[1]
+    if pad:
+        context = torch.cat([context, context.new_zeros(context.shape[0], pad, context.shape[2])], 1)
+        context_mask = torch.cat([context_mask, context_mask.new_zeros(context_mask.shape[0], pad)], 1)
+    q = _AllGatherRows.apply(query.contiguous(), nq)
+    c = _AllGatherRows.apply(context.contiguous(), nv)
+    m = _AllGatherRows.apply(context_mask.contiguous(), nv)
+    return q, c, m
+
+
+# ---- pickled-object helpers (utils/distributed.py:182-212) ------------------------------------
+def all_gather_list(data):
+    if world_size() == 1:
+        return [data]
+    out = [None] * world_size()
+    dist.all_gather_object(out, data)
+    return out
+
+
+def any_broadcast(data, root_rank):
+    if world_size() == 1:
+        return data
+    box = [data if rank() == root_rank else None]
+    dist.broadcast_object_list(box, src=root_rank)
+    return box[0]
+
+
+__all__ = ["all_reduce_and_rescale_tensors", "broadcast_tensors", "GradArena", "gather_negatives",
+           "all_gather_list", "any_broadcast", "world_size", "rank", "pickle"]

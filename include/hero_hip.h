@@ -1,0 +1,208 @@
+/* hero_hip.h — C ABI of libhero_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * HERO hierarchical-encoder hot path (linjieli222/HERO: model/layers.py, model/encoder.py,
+ * model/embed.py, model/model.py, optim/adamw.py).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no framework types; every pointer is DEVICE memory unless noted;
+ *   - every entry point returns 0 on success or a negative HERO_ERR_* code; the message is
+ *     available from hero_last_error() (thread-local, valid until the next failing call);
+ *   - nothing allocates, nothing synchronises: work is enqueued on `stream` (a hipStream_t);
+ *     scratch memory is passed in by the caller (see the *_workspace_bytes queries);
+ *   - `dtype` is the ACTIVATION element type: HERO_F32 (exact-f32 MFMA path used for the parity
+ *     gate) or HERO_BF16 (bf16 storage + bf16 MFMA, fp32 accumulation). Parameters that are
+ *     small (bias, LayerNorm affine, embedding tables) are always fp32; GEMM weight operands are
+ *     in the activation dtype; parameter gradients are always fp32;
+ *   - row-major everywhere, leading dimensions in ELEMENTS.
+ *
+ * Each declaration cites the reference code (file:line in linjieli222/HERO) it replaces.
+ */
+#ifndef HERO_HIP_H_
+#define HERO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hero_stream_t; /* hipStream_t */
+
+enum { HERO_F32 = 0, HERO_BF16 = 1 };
+enum { HERO_OK = 0, HERO_ERR_ARG = -1, HERO_ERR_LAUNCH = -2, HERO_ERR_UNSUPPORTED = -3 };
+
+const char* hero_last_error(void);
+int hero_abi_version(void);
+
+/* Counter-based dropout. keep(element) is a pure function of (*seed_ptr, site, element index), so
+ * the backward kernels regenerate the forward mask instead of loading one. threshold16 = round(p *
+ * 65536) (0 disables), scale = 1/(1-p). seed_ptr points to ONE device uint64 that the host
+ * advances per step (it stays valid under hipGraph replay); site distinguishes call sites.
+ * Replaces torch.nn.Dropout at model/layers.py:149,177,252,80-84 and model/embed.py:57,116,160. */
+typedef struct HeroDropout {
+  const uint64_t* seed_ptr;
+  uint64_t site;
+  uint32_t threshold16;
+  float scale;
+} HeroDropout;
+
+/* ------------------------------------------------------------------------------------------ */
+/* GEMM with fused epilogue — nn.Linear forward / dgrad / wgrad                                 */
+/*   model/layers.py:125-127 (Q,K,V), :176 (attention out), :237 (FFN1), :251 (FFN2), :90       */
+/*   (LinearLayer), model/embed.py:110 (img_linear) and their autograd transposes.              */
+/* ------------------------------------------------------------------------------------------ */
+enum { HERO_LAYOUT_K = 0, /* operand is [outer, reduction], reduction contiguous          */
+       HERO_LAYOUT_O = 1  /* operand is [reduction, outer], outer (M or N) contiguous     */ };
+enum { HERO_ACT_NONE = 0,
+       HERO_ACT_GELU = 1,     /* fwd: aux <- acc+bias (pre-activation), out <- gelu_erf(.)     */
+       HERO_ACT_RELU = 2,     /* fwd: out <- relu(acc+bias); aux <- that value (pre-residual) */
+       HERO_ACT_GELU_BWD = 3, /* bwd: out <- acc * gelu_erf'(aux)                              */
+       HERO_ACT_RELU_BWD = 4  /* bwd: out <- acc * (aux > 0)                                   */ };
+
+typedef struct HeroGemmEpilogue {
+  const float* bias;    /* [N] fp32 or NULL                                                  */
+  const void* residual; /* [M, ldc] activation dtype or NULL; added last                     */
+  void* aux;            /* [M, ldc] activation dtype; meaning depends on `act`               */
+  int act;              /* HERO_ACT_*                                                        */
+  int out_f32;          /* 1: C is fp32 regardless of dtype (wgrad)                          */
+  float beta;           /* out_f32 only: C <- result + beta * C                              */
+  int split_k;          /* >1: reduction split over blocks, fp32 atomics into C (needs       */
+                        /*     out_f32, act NONE, no bias/residual/dropout; C pre-scaled)    */
+  HeroDropout dropout;  /* applied after bias/act, before residual; index = m*N + n          */
+} HeroGemmEpilogue;
+
+/* C[M,N] = op(A)[M,K] * op(B)[K,N] (+ epilogue).
+ *   a_layout K: A is [M, lda] ; O: A is [K, lda] (wgrad: dY^T)
+ *   b_layout K: B is [N, ldb] (nn.Linear weight, x @ W^T) ; O: B is [K, ldb] (dgrad / wgrad)
+ * Constraints: bf16: K-layout operands need K % 8 == 0, O-layout operands need their outer dim % 8
+ * == 0; f32: % 4. N % 4 == 0. All base pointers 16-byte aligned, lda/ldb/ldc multiples of that
+ * vector width. */
+int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+              int a_layout, int b_layout, int dtype, const HeroGemmEpilogue* epi, hero_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* LayerNorm (apex FusedLayerNorm call sites: model/layers.py:52,79,171,246,338,               */
+/* model/embed.py:25,93,99,143,171) fused with the embedding sums in front of it               */
+/* (model/embed.py:28-58 SubEmbeddings, :102-117 ImageEmbeddings, :146-161 FrameEmbeddings)     */
+/* and the dropout behind it.                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct HeroLnFwd {
+  const void* x;        /* [rows, cols] x_dtype, or NULL                                       */
+  const float* tab[3];  /* fp32 tables [*, cols] gathered and added to x (NULL = unused)        */
+  const int32_t* idx[3];/* per-row table row; NULL = row 0 for every row                       */
+  const float* gamma;   /* [cols] */
+  const float* beta;    /* [cols] */
+  void* y;              /* [rows, cols] y_dtype                                                */
+  void* pre;            /* optional [rows, cols] y_dtype: the summed LN input (for backward)   */
+  float* mean;          /* optional [rows] */
+  float* rstd;          /* optional [rows] */
+  int rows, cols;
+  float eps;
+  int x_dtype, y_dtype;
+  HeroDropout dropout;  /* on y; index = row*cols + col                                         */
+} HeroLnFwd;
+int hero_layernorm_fwd(const HeroLnFwd* a, hero_stream_t stream);
+
+typedef struct HeroLnBwd {
+  const void* x;        /* [rows, cols] x_dtype: the LN input (or `pre` saved by forward)       */
+  const void* dy;       /* [rows, cols] dtype                                                   */
+  const float* gamma;
+  const float* mean;
+  const float* rstd;
+  void* dx;             /* optional [rows, cols] dtype                                          */
+  void* dx_dropped;     /* optional [rows, cols] dtype: dx * mask(dropout_in) — the gradient    */
+                        /* of the pre-dropout branch feeding this LN's residual sum             */
+  float* dgamma;        /* optional [cols]: dgamma <- grad_beta*dgamma + sum                    */
+  float* dbeta;         /* optional [cols]                                                      */
+  float grad_beta;      /* 0 overwrite, 1 accumulate                                            */
+  void* workspace;      /* hero_layernorm_bwd_workspace_bytes(rows, cols) bytes                 */
+  int rows, cols;
+  int x_dtype, dtype;
+  HeroDropout dropout_out; /* the forward's output dropout (applied to dy first)                */
+  HeroDropout dropout_in;  /* dropout of the GEMM epilogue that produced x (for dx_dropped)     */
+} HeroLnBwd;
+size_t hero_layernorm_bwd_workspace_bytes(int rows, int cols);
+int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream);
+
+/* Column sum: out[c] <- beta*out[c] + sum_r x[r, c]  (bias gradients of every nn.Linear).      */
+size_t hero_colsum_workspace_bytes(int rows, int cols);
+int hero_colsum(const void* x, float* out, int rows, int cols, int ld, int dtype, float beta,
+                void* workspace, hero_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Masked multi-head self-attention, head size 64 — model/layers.py:129-160                     */
+/*   scores = Q K^T * scale + mask[s, key]; P = softmax(scores); ctx = dropout(P) V             */
+/* qkv is the fused projection output [S*L, 3*H*64] (Q | K | V, head h at columns h*64).        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct HeroAttn {
+  const void* qkv;    /* [S*L, 3*H*64] dtype                                                   */
+  const float* mask;  /* [S, L] additive fp32 ((1-m)*-10000, model/layers.py:299-302) or NULL   */
+  void* ctx;          /* fwd out [S*L, H*64] dtype                                              */
+  float* probs;       /* [S, H, L, L] fp32 softmax output (pre-dropout); fwd out (may be NULL   */
+                      /* for inference), bwd in                                                 */
+  const void* dctx;   /* bwd in  [S*L, H*64] dtype                                              */
+  void* dqkv;         /* bwd out [S*L, 3*H*64] dtype                                            */
+  int S, L, H;
+  float scale;        /* 1/sqrt(64)                                                             */
+  int dtype;
+  HeroDropout dropout; /* on P; index = ((s*H+h)*L + q)*round_up(L,4) + k                       */
+} HeroAttn;
+int hero_attention_fwd(const HeroAttn* a, hero_stream_t stream);
+int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream);
+int hero_attention_max_len(int dtype, int backward);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row gathers / scatters                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* out[r] = idx[r] >= 0 ? a[idx[r]] : (idx[r] == -1 ? 0 : b[-idx[r]-2]).                         */
+/* Replaces torch.gather(cat([img_emb, txt_emb]), gather_index) (model/encoder.py:271-279) and  */
+/* serves as the backward of hero_csr_gather_sum.                                               */
+int hero_gather_rows(const void* a, const void* b, const int32_t* idx, void* out, int rows, int cols,
+                     int dtype, hero_stream_t stream);
+/* out[r] = sum_{e in [offsets[r], offsets[r+1])} src[entries[e]].                               */
+/* Replaces HierarchicalVlModel.collect_frame_outputs (model/model.py:156-187).                 */
+int hero_csr_gather_sum(const void* src, const int32_t* offsets, const int32_t* entries, void* out,
+                        int rows, int cols, int dtype, hero_stream_t stream);
+/* dst[idx[r]] += src[r] (rows with idx[r] < 0 or == skip_idx are dropped).                      */
+/* dst_dtype HERO_F32: embedding-table gradients (nn.Embedding backward, padding_idx = skip).   */
+/* Two destinations as in hero_gather_rows when b != NULL.                                      */
+int hero_scatter_add_rows(const void* src, const int32_t* idx, void* dst_a, void* dst_b, int rows,
+                          int cols, int src_dtype, int dst_dtype, int skip_idx, hero_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Elementwise                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+/* dst <- (dst_dtype) src, n elements (fp32 master weights -> compute copies, outputs -> fp32). */
+int hero_cast(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, hero_stream_t stream);
+/* dx <- dy * (y > 0) — F.relu backward (model/layers.py:92).                                   */
+int hero_relu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, hero_stream_t stream);
+/* dx <- dy * gelu_erf'(u) — backward of model/layers.py:16-25 outside the fused FFN block.     */
+int hero_gelu_bwd(const void* dy, const void* u, void* dx, size_t n, int dtype, hero_stream_t stream);
+/* y <- a + b (gradient fan-in where two consumers read one activation).                        */
+int hero_add(const void* a, const void* b, void* y, size_t n, int dtype, hero_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Optimiser — optim/adamw.py:43-106 + clip_grad_norm_ (train_vcmr.py:257-260) over flat fp32   */
+/* parameter / gradient arenas.                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+/* sumsq[0] += sum g^2 (fp32 device scalar; caller zeroes it).                                   */
+int hero_sumsq(const float* g, size_t n, float* sumsq, hero_stream_t stream);
+typedef struct HeroAdamW {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  size_t n;
+  float lr, beta1, beta2, eps, weight_decay;
+  int step;                /* 1-based, for bias correction                                     */
+  const float* grad_sumsq; /* optional device scalar: global sum g^2 for clipping               */
+  float max_grad_norm;     /* used when grad_sumsq != NULL: g *= min(1, max/(norm+1e-6))        */
+  float grad_scale;        /* extra multiplier on g (e.g. 1/world_size); 1 = none               */
+  void* shadow;            /* optional bf16 copy of p refreshed in the same pass               */
+} HeroAdamW;
+int hero_adamw(const HeroAdamW* a, hero_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HERO_HIP_H_ */

@@ -1,0 +1,146 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol
+include/hero_hip.h declares, state-dict schema equals the reference's, host index logic is right,
+and the product path refuses to run without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hero_oracle as O
+from tests.util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from hero_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "hero_hip.h")).read()
+    declared = set(re.findall(r"\b(hero_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    handle = ctypes.CDLL(built_lib)
+    missing = [s for s in sorted(declared) if not hasattr(handle, s)]
+    assert not missing, missing
+    from hero_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+    handle.hero_abi_version.restype = ctypes.c_int
+    assert handle.hero_abi_version() == 1
+
+
+def test_struct_layouts_match_header_sizes(built_lib):
+    """ctypes mirrors must have the C sizes (checked against sizes computed by gcc)."""
+    import subprocess
+    import tempfile
+    from hero_amd import _lib
+    src = '#include <stdio.h>\n#include "hero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",' \
+          'sizeof(HeroDropout),sizeof(HeroGemmEpilogue),sizeof(HeroLnFwd),sizeof(HeroLnBwd),' \
+          'sizeof(HeroAttn),sizeof(HeroAdamW));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "s.c"), "w") as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"),
+                               "-o", os.path.join(d, "s")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
+    mine = [ctypes.sizeof(c) for c in (_lib.Dropout, _lib.GemmEpilogue, _lib.LnFwd, _lib.LnBwd,
+                                       _lib.Attn, _lib.AdamW)]
+    assert mine == sizes
+
+
+def test_state_dict_schema_equals_reference():
+    from hero_amd.model import HeroForVcmr
+    z = np.load(os.path.join(GOLDEN, "tiny_model.npz"))
+    ref = {k: tuple(z[k].shape) for k in z.files if not k.startswith("__")}
+    m = HeroForVcmr.from_pretrained(os.path.join(GOLDEN, "tiny_config.json"), {}, vfeat_dim=96,
+                                    max_frm_seq_len=16, lw_neg_ctx=8.0, lw_neg_q=8.0)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref
+    # tied decoder / word embedding (model/layers.py:342-345)
+    fe = m.v_encoder.f_encoder
+    assert fe.lm_head.decoder.weight is fe.embeddings.word_embeddings.weight
+    # default LayerNorm eps: 1e-12 in encoder layers, 1e-5 elsewhere (SURVEY §8 a'.3)
+    assert fe.encoder.layer[0].output.LayerNorm.eps == 1e-12
+    assert fe.embeddings.LayerNorm.eps == 1e-5 and m.v_encoder.frame_transform.LayerNorm.eps == 1e-5
+
+
+def test_pad_vocab_and_partial_checkpoint():
+    from hero_amd.model.modeling_utils import load_partial_checkpoint, pad_tensor_to_mul
+    t, n = pad_tensor_to_mul(torch.ones(50265, 4))
+    assert t.shape[0] == 50272 and n == 7 and float(t[50265:].abs().sum()) == 0
+    t, n = pad_tensor_to_mul(torch.ones(16, 4))
+    assert n == 0 and t.shape[0] == 16
+    ck = {"roberta.encoder.layer.%d.w" % i: i for i in range(12)}
+    ck["roberta.embeddings.x"] = -1
+    out = load_partial_checkpoint(ck, 6)
+    assert out == {**{"roberta.encoder.layer.%d.w" % j: 2 * j + 1 for j in range(6)}, "roberta.embeddings.x": -1}
+
+
+def test_frame_map_matches_reference_collect():
+    from hero_amd.model.model import build_frame_map
+    batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_ragged.npz"))
+    T, L = batch["f_attn_masks"].shape
+    B, NF = batch["c_v_feats"].shape[:2]
+    offs, ent, inv = build_frame_map(batch["num_subs"], batch["sub_idx2frame_idx"], B, NF, L, "cpu")
+    f_seq = torch.randn(T, L, 8)
+    want = O.collect_frame_outputs(f_seq, batch["num_subs"], batch["sub_idx2frame_idx"], B, NF)
+    flat = f_seq.reshape(T * L, 8)
+    got = torch.zeros(B * NF, 8)
+    for r in range(B * NF):
+        for e in range(int(offs[r]), int(offs[r + 1])):
+            got[r] += flat[int(ent[e])]
+    torch.testing.assert_close(got.view(B, NF, 8), want)
+    for s, d in enumerate(inv.tolist()):
+        if d >= 0:
+            assert s in ent[int(offs[d]):int(offs[d + 1])].tolist()
+
+
+def test_flat_gather_index_matches_torch_gather():
+    from hero_amd.model.encoder import CrossModalTrm
+    batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_ragged.npz"))
+    gi = batch["f_gather_index"]
+    T = gi.shape[0]
+    max_vl, max_sl = batch["f_v_feats"].shape[1], batch["f_sub_input_ids"].shape[1]
+    img, txt = torch.randn(T, max_vl, 4), torch.randn(T, max_sl, 4)
+    want = torch.gather(torch.cat([img, txt], 1), 1, gi.unsqueeze(-1).expand(-1, -1, 4))
+    flat = CrossModalTrm._flat_gather_index(gi, max_vl, max_sl).long()
+    a, b = img.reshape(-1, 4), txt.reshape(-1, 4)
+    got = torch.where((flat >= 0)[:, None], a[flat.clamp(min=0)], b[(-flat - 2).clamp(min=0)])
+    torch.testing.assert_close(got.view(T, -1, 4), want)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU instead of silently computing something else."""
+    from hero_amd import functional as HF
+    from tests.util import load_tiny
+    with pytest.raises(RuntimeError, match="no CPU fallback|CUDA"):
+        HF.k_cast(torch.zeros(8), torch.bfloat16)
+    model, _, _ = load_tiny("cpu")
+    batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_regular.npz"))
+    with pytest.raises(RuntimeError):
+        model.v_encoder(batch, "repr")
+
+
+def test_synth_batch_contract():
+    """Synthetic batches carry the reference collate's keys/shapes/dtypes (data/data.py:459-470)."""
+    from hero_amd.synth import make_batch
+    b = make_batch("D1", vfeat_dim=32, vocab=100)
+    assert b["f_v_feats"].shape == (16, 4, 32) and b["f_sub_input_ids"].shape == (16, 8)
+    assert b["f_attn_masks"].shape == (16, 12) and b["c_v_feats"].shape == (2, 32, 32)
+    assert b["f_gather_index"].dtype == torch.int64 and b["f_sub_input_ids"][:, 0].eq(2).all()
+    assert b["query_input_ids"].shape == (2, 12) and b["query_input_ids"][:, 0].eq(0).all()
+    assert b["num_subs"] == [8, 8] and all(s == i for v in b["sub_idx2frame_idx"] for i, (s, _) in enumerate(v))
+    r = make_batch("D2", vfeat_dim=8, vocab=100, ragged=True, videos=4)
+    assert r["f_attn_masks"].shape[0] == sum(r["num_subs"])
+    # a subtitle with no frame: zero feature row, first mask bit 0 (data/data.py:380-382)
+    row = 0
+    for v in r["sub_idx2frame_idx"]:
+        for _, fr in v:
+            if not fr:
+                assert r["f_attn_masks"][row, 0] == 0 and r["f_v_feats"][row].abs().sum() == 0
+            row += 1

@@ -1,0 +1,264 @@
+"""Kernel-level parity: every C-ABI op against a plain fp32 torch restatement of the same op on
+the same seeded inputs.  Needs a real MI355X (-m gpu)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+# written tolerances: fp32 path = exact-f32 MFMA / fp32 VALU (only summation order differs);
+# bf16 path = bf16 storage of inputs/outputs (2^-9 relative per rounding), fp32 accumulation.
+TOL = {torch.float32: dict(rtol=2e-5, atol=2e-5), torch.bfloat16: dict(rtol=2e-2, atol=2e-2)}
+
+
+@pytest.fixture(scope="module")
+def HF():
+    from hero_amd import functional
+    return functional
+
+
+@pytest.fixture(scope="module")
+def Lb():
+    from hero_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def close(a, b, dtype, scale=1.0):
+    t = TOL[dtype]
+    torch.testing.assert_close(a.float(), b.float(), rtol=t["rtol"], atol=t["atol"] * scale)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 96), (1, 8, 8), (515, 768, 768),
+                                   (480, 3072, 768), (131, 768, 4352)])
+def test_gemm_forward_epilogues(HF, Lb, dtype, M, N, K):
+    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
+    res = rnd(M, N, dtype=dtype, seed=4)
+    ref = x.float() @ w.float().t() + b
+    y = HF.k_linear(x, w, b)
+    close(y, ref, dtype, scale=math.sqrt(K) * 0.05)
+    aux = torch.empty_like(y)
+    y = HF.k_linear(x, w, b, act=Lb.ACT_GELU, aux=aux)
+    close(aux, ref, dtype, scale=math.sqrt(K) * 0.05)
+    close(y, torch.nn.functional.gelu(ref), dtype, scale=math.sqrt(K) * 0.05)
+    aux = torch.empty_like(y)
+    y = HF.k_linear(x, w, b, act=Lb.ACT_RELU, aux=aux, residual=res)
+    close(aux, torch.relu(ref), dtype, scale=math.sqrt(K) * 0.05)
+    close(y, torch.relu(ref) + res.float(), dtype, scale=math.sqrt(K) * 0.05 + 1)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (203, 136, 96), (515, 768, 3072), (4000, 768, 768)])
+def test_gemm_dgrad_wgrad(HF, Lb, dtype, M, N, K):
+    """dgrad: dy[M,N] @ W[N,K]; wgrad: dy^T @ x (fp32 out, split-K atomics for large M)."""
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05)
+    dy = rnd(M, N, dtype=dtype, seed=5)
+    u = rnd(M, K, dtype=dtype, seed=6)
+    r = rnd(M, K, dtype=dtype, seed=7)
+    dx = HF.k_dgrad(dy, w)
+    close(dx, dy.float() @ w.float(), dtype, scale=math.sqrt(N) * 0.05)
+    dxg = HF.k_dgrad(dy, w, act=Lb.ACT_GELU_BWD, aux=u, residual=r)
+    uf = u.float()
+    gp = 0.5 * (1 + torch.erf(uf / math.sqrt(2))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2 * math.pi)
+    close(dxg, (dy.float() @ w.float()) * gp + r.float(), dtype, scale=math.sqrt(N) * 0.05 + 1)
+    dW = HF.k_wgrad(dy, x)
+    assert dW.dtype == torch.float32
+    torch.testing.assert_close(dW, dy.float().t() @ x.float(), rtol=1e-4, atol=1e-3 * math.sqrt(M))
+    close(HF.k_colsum(dy), dy.float().sum(0), torch.float32, scale=math.sqrt(M) * (1 if dtype == torch.float32 else 1))
+
+
+def test_gemm_transpose_detecting(HF, Lb):
+    """A = I with an asymmetric B catches row/column swaps in the MFMA fragment maps."""
+    for dtype in DT:
+        n = 128
+        eye = torch.eye(n, dtype=dtype).cuda()
+        b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(dtype).cuda()
+        y = HF.k_linear(eye, b)          # I @ b^T
+        torch.testing.assert_close(y.float(), b.float().t())
+        y2 = HF.k_dgrad(eye, b)          # I @ b
+        torch.testing.assert_close(y2.float(), b.float())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols", [(37, 128), (1000, 768), (64, 4352), (5, 1536)])
+def test_layernorm(HF, dtype, rows, cols):
+    x = rnd(rows, cols, dtype=dtype, seed=1) * 2 + 0.5
+    g, b = rnd(cols, seed=2) * 0.1 + 1, rnd(cols, seed=3) * 0.1
+    dy = rnd(rows, cols, dtype=dtype, seed=4)
+    for eps in (1e-12, 1e-5):
+        y, mean, rstd, _ = HF.k_ln_fwd(x, g, b, eps, dtype, rows, cols)
+        xf = x.float().requires_grad_(True)
+        gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(xf, (cols,), gf, bf, eps)
+        close(y, ref, dtype, scale=3)
+        ref.backward(dy.float())
+        dx, _, dg, db = HF.k_ln_bwd(x, dy, g, mean, rstd)
+        close(dx, xf.grad, dtype, scale=3)
+        torch.testing.assert_close(dg, gf.grad, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=0.3 if dtype == torch.bfloat16 else 1e-3)
+        torch.testing.assert_close(db, bf.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_layernorm_fp32_in_bf16_out_and_tables(HF):
+    rows, cols = 300, 768
+    x = rnd(rows, cols, seed=1)
+    g, b = rnd(cols, seed=2) * 0.1 + 1, rnd(cols, seed=3) * 0.1
+    t0, t1 = rnd(50, cols, seed=4), rnd(7, cols, seed=5)
+    i0 = torch.randint(0, 50, (rows,), generator=torch.Generator().manual_seed(6)).int().cuda()
+    i1 = torch.randint(0, 7, (rows,), generator=torch.Generator().manual_seed(7)).int().cuda()
+    for od in DT:
+        y, mean, rstd, pre = HF.k_ln_fwd(x, g, b, 1e-5, od, rows, cols, tabs=[t0, t1, t1[3:4]],
+                                         idxs=[i0, i1, None], want_pre=True)
+        s = x + t0[i0.long()] + t1[i1.long()] + t1[3]
+        close(pre, s, od)
+        close(y, torch.nn.functional.layer_norm(s, (cols,), g, b, 1e-5), od, scale=3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("S,L,H", [(3, 9, 2), (5, 24, 12), (2, 60, 12), (2, 100, 3), (1, 130, 2)])
+def test_attention_fwd_bwd(HF, dtype, S, L, H):
+    D = H * 64
+    qkv = rnd(S * L, 3 * D, dtype=dtype, seed=1)
+    lens = [max(1, L - 3 * i) for i in range(S)]
+    m = torch.zeros(S, L)
+    for i, n in enumerate(lens):
+        m[i, :n] = 1
+    if S > 1:
+        m[1, 0] = 0                                   # subtitle without frames: first key masked
+    madd = ((1 - m) * -10000.0).cuda()
+    dctx = rnd(S * L, D, dtype=dtype, seed=2)
+    ctx, probs = HF.k_attn_fwd(qkv, madd, S, L, H)
+    q = qkv.float().requires_grad_(True)
+    qq, kk, vv = [t.reshape(S, L, H, 64).permute(0, 2, 1, 3) for t in q.split(D, dim=1)]
+    sc = qq @ kk.transpose(-1, -2) / 8.0 + madd[:, None, None, :]
+    pr = torch.softmax(sc, -1)
+    ref = (pr @ vv).permute(0, 2, 1, 3).reshape(S * L, D)
+    torch.testing.assert_close(probs, pr, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-3)
+    close(ctx, ref, dtype)
+    ref.backward(dctx.float())
+    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, L, H)
+    close(dqkv, q.grad, dtype, scale=2)
+
+
+def test_attention_dropout_adjoint(HF, Lb):
+    """With dropout on, forward is linear in V for a fixed mask and backward must use the SAME mask:
+    <dctx, ctx(V)> == <dV, V>.  Also the keep rate is 1-p."""
+    S, L, H, D = 4, 40, 2, 128
+    qkv = rnd(S * L, 3 * D, seed=1)
+    drop = HF.RNG.make(0.25, True, qkv.device)
+    ctx, probs = HF.k_attn_fwd(qkv, None, S, L, H, drop=drop)
+    ctx2, _ = HF.k_attn_fwd(qkv, None, S, L, H, drop=drop)
+    torch.testing.assert_close(ctx, ctx2)                       # same site -> same mask
+    ctx0, _ = HF.k_attn_fwd(qkv, None, S, L, H)
+    assert (ctx - ctx0).abs().max() > 1e-3
+    dctx = rnd(S * L, D, seed=2)
+    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, L, H, drop=drop)
+    v = qkv[:, 2 * D:]
+    lhs = (dctx * ctx).sum()
+    rhs = (dqkv[:, 2 * D:] * v).sum()
+    torch.testing.assert_close(lhs, rhs, rtol=1e-3, atol=1e-2)
+    # keep-rate through a GEMM epilogue: ones @ I with dropout -> entries are 0 or 1/(1-p)
+    n = 256
+    y = torch.empty(n, n, device="cuda")
+    HF.k_gemm(torch.eye(n).cuda(), torch.ones(n, n).cuda(), y, n, n, n, n, n, n, Lb.LAYOUT_K, Lb.LAYOUT_K,
+              Lb.F32, drop=HF.RNG.make(0.1, True, y.device))
+    kept = (y > 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01, kept
+    vals = torch.unique(y)
+    assert len(vals) == 2 and abs(vals.max().item() - 1 / 0.9) < 1e-5
+
+
+def test_ln_bwd_dropout_consistency(HF, Lb):
+    """ProjResLn: dx_dropped must equal dx * (the GEMM epilogue's mask)."""
+    M, N, K = 300, 256, 128
+    x, w, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    drop = HF.RNG.make(0.3, True, x.device)
+    y = HF.k_linear(x, w, b, residual=res, drop=drop)
+    z = x @ w.t() + b
+    mask = ((y - res).abs() > 1e-6).float()          # kept positions (z != 0 almost surely)
+    torch.testing.assert_close(y, z * mask / 0.7 + res, rtol=1e-4, atol=1e-4)
+    g, bt = rnd(N, seed=5) * 0.1 + 1, rnd(N, seed=6)
+    out, mean, rstd, _ = HF.k_ln_fwd(y, g, bt, 1e-12, torch.float32, M, N)
+    dy = rnd(M, N, seed=7)
+    dx, dxd, _, _ = HF.k_ln_bwd(y, dy, g, mean, rstd, drop_in=drop)
+    torch.testing.assert_close(dxd, dx * mask / 0.7, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gather_scatter(HF, dtype):
+    a, b = rnd(50, 128, dtype=dtype, seed=1), rnd(30, 128, dtype=dtype, seed=2)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(-31, 50, (200,), generator=g).int()
+    idx[idx == -1] = 5
+    idx[::17] = -1
+    idx = idx.cuda()
+    out = HF.k_gather_rows(a, b, idx, 200, 128)
+    li = idx.long()
+    ref = torch.where((li >= 0)[:, None], a[li.clamp(min=0)].float(),
+                      torch.where((li == -1)[:, None], torch.zeros(1, 128, device="cuda"),
+                                  b[(-li - 2).clamp(min=0)].float()))
+    torch.testing.assert_close(out.float(), ref)
+    da, db = torch.zeros_like(a), torch.zeros_like(b)
+    src = rnd(200, 128, dtype=dtype, seed=4)
+    HF.k_scatter_add(src, idx, da, db)
+    ra, rb = torch.zeros(50, 128, device="cuda"), torch.zeros(30, 128, device="cuda")
+    ra.index_add_(0, li[li >= 0], src.float()[li >= 0])
+    rb.index_add_(0, (-li - 2)[li <= -2], src.float()[li <= -2])
+    close(da, ra, dtype, scale=4)
+    close(db, rb, dtype, scale=4)
+    tab = torch.zeros(50, 128, device="cuda")
+    HF.k_scatter_add(src, idx.clamp(min=0), tab, None, skip=5)
+    rt = torch.zeros(50, 128, device="cuda")
+    keep = li.clamp(min=0) != 5
+    rt.index_add_(0, li.clamp(min=0)[keep], src.float()[keep])
+    torch.testing.assert_close(tab, rt, rtol=1e-5, atol=1e-5)
+
+
+def test_csr_gather_and_elementwise(HF, Lb):
+    from hero_amd.model.model import build_frame_map
+    num_subs = [2, 1]
+    sub2frm = [[(0, [0, 1]), (1, [3])], [(0, [2, 0])]]
+    offs, ent, inv = build_frame_map(num_subs, sub2frm, 2, 4, 5, torch.device("cuda"))
+    src = rnd(3 * 5, 64, seed=1).requires_grad_(True)
+    out = HF.CsrGatherSumFn.apply(src, offs, ent, inv, 8)
+    ref = torch.zeros(8, 64, device="cuda")
+    ref[0], ref[1], ref[3] = src[0], src[1], src[5]
+    ref[4 + 2], ref[4 + 0] = src[10], src[11]
+    torch.testing.assert_close(out, ref)
+    out.backward(torch.ones_like(out) * 2)
+    expect = torch.zeros(15, 64, device="cuda")
+    expect[[0, 1, 5, 10, 11]] = 2
+    torch.testing.assert_close(src.grad, expect)
+    x = rnd(1001, seed=2)
+    torch.testing.assert_close(HF.k_cast(HF.k_cast(x, torch.bfloat16), torch.float32), x.bfloat16().float())
+
+
+def test_adamw_matches_oracle(HF, Lb):
+    from oracle import hero_oracle as O
+    from hero_amd.optim import AdamW
+    p0, g = rnd(1000, 33, seed=1), rnd(1000, 33, seed=2)
+    p = torch.nn.Parameter(p0.clone())
+    opt = AdamW([{"params": [p], "weight_decay": 0.01}], lr=1e-3, betas=(0.9, 0.98))
+    P = {"w": p0.clone().cpu()}
+    state = {}
+    for step in (1, 2, 3):
+        p.grad = g * step
+        opt.step()
+        O.adamw_step(P, {"w": (g * step).cpu()}, state, lr=1e-3, step=step)
+    torch.testing.assert_close(p.detach().cpu(), P["w"], rtol=1e-5, atol=1e-6)
+    # fused clip: norm > max -> grads scaled by max/(norm+1e-6)
+    q = torch.nn.Parameter(p0.clone())
+    opt2 = AdamW([{"params": [q], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.98))
+    q.grad = g.clone()
+    opt2.step(grad_sumsq=opt2.grad_sumsq(), max_grad_norm=1.0)
+    P2, st2 = {"w": p0.clone().cpu()}, {}
+    gn = g.norm().cpu()
+    O.adamw_step(P2, {"w": g.cpu() * (1.0 / (gn + 1e-6))}, st2, lr=1e-3, step=1, wd=0.0)
+    torch.testing.assert_close(q.detach().cpu(), P2["w"], rtol=1e-5, atol=1e-6)

@@ -14,6 +14,7 @@
 // double-buffered, one barrier per K tile. The epilogue goes through LDS so that bias / residual /
 // aux / output traffic is 8-16 B per lane and coalesced along N.
 #include "common.h"
+#include <vector>
 
 namespace hero {
 
@@ -343,6 +344,14 @@ __global__ void scale_f32_kernel(float* c, int M, int N, int ldc, float beta) {
   }
 }
 
+// ---- optional per-launch timing with HIP events (bench.py roofline leg) ----------------------------
+struct ProfSlot {
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  std::vector<double> flops;
+};
+static ProfSlot g_prof[8];
+static bool g_prof_on = false;
+
 template <typename T, int AL, int BL>
 static int launch(const GemmArgs& g, hipStream_t s) {
   static bool attr_set = false;
@@ -352,7 +361,23 @@ static int launch(const GemmArgs& g, hipStream_t s) {
   }
   const int split = g.epi.split_k > 1 ? g.epi.split_k : 1;
   const int grid = g.tiles_m * g.tiles_n * split;
+  ProfSlot* ps = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof_on) {
+    ps = &g_prof[(sizeof(T) == 2 ? 4 : 0) + AL * 2 + BL];
+    if (ps->flops.size() < 16384 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      (void)hipEventRecord(e0, s);
+    } else {
+      ps = nullptr;
+    }
+  }
   hipLaunchKernelGGL((gemm_kernel<T, AL, BL>), dim3(grid), dim3(NT), 65536, s, g);
+  if (ps) {
+    (void)hipEventRecord(e1, s);
+    ps->ev.push_back(e0);
+    ps->ev.push_back(e1);
+    ps->flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
+  }
   return check_launch("hero_gemm");
 }
 
@@ -418,4 +443,34 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   g.k_per_split = K > 0 ? ((K + bk - 1) / bk) * bk : bk;
   g.epi.split_k = 1;
   return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, s) : dispatch<float>(g, a_layout, b_layout, s);
+}
+
+// Per-launch timing of the GEMM kernels with HIP events on the launch stream (used by bench.py
+// for the roofline leg). slot = (dtype == BF16 ? 4 : 0) + a_layout * 2 + b_layout.
+extern "C" int hero_prof_enable(int on) {
+  for (auto& p : g_prof) {
+    for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    p.ev.clear();
+    p.flops.clear();
+  }
+  g_prof_on = on != 0;
+  return HERO_OK;
+}
+extern "C" int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches) {
+  HERO_REQUIRE(slot >= 0 && slot < 8 && total_ms && total_flops && launches, "hero_prof_read: bad arguments");
+  ProfSlot& p = g_prof[slot];
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < p.flops.size(); ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) {
+      set_error("hero_prof_read: event query failed");
+      return HERO_ERR_LAUNCH;
+    }
+    ms += t;
+    fl += p.flops[i];
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = (long long)p.flops.size();
+  return HERO_OK;
 }

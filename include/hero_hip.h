@@ -80,6 +80,12 @@ typedef struct HeroGemmEpilogue {
 int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
               int a_layout, int b_layout, int dtype, const HeroGemmEpilogue* epi, hero_stream_t stream);
 
+/* Per-launch timing of hero_gemm with HIP events recorded on the launch stream (bench.py's
+ * roofline leg; off by default, never enable inside graph capture).
+ * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout. hero_prof_read synchronises. */
+int hero_prof_enable(int on);
+int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches);
+
 /* ------------------------------------------------------------------------------------------ */
 /* LayerNorm (apex FusedLayerNorm call sites: model/layers.py:52,79,171,246,338,               */
 /* model/embed.py:25,93,99,143,171) fused with the embedding sums in front of it               */

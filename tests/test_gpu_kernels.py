@@ -95,7 +95,7 @@ def test_layernorm(HF, dtype, rows, cols):
     dy = rnd(rows, cols, dtype=dtype, seed=4)
     for eps in (1e-12, 1e-5):
         y, mean, rstd, _ = HF.k_ln_fwd(x, g, b, eps, dtype, rows, cols)
-        xf = x.float().requires_grad_(True)
+        xf = x.float().clone().requires_grad_(True)
         gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
         ref = torch.nn.functional.layer_norm(xf, (cols,), gf, bf, eps)
         close(y, ref, dtype, scale=3)

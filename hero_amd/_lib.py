@@ -20,7 +20,7 @@ EXPORTS = [
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast",
-    "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw",
+    "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
 ]
 
 
@@ -67,6 +67,22 @@ class AdamW(C.Structure):
                 ("grad_scale", C.c_float), ("shadow", C.c_void_p)]
 
 
+class TensorDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("n", C.c_uint64), ("group", C.c_int32), ("step_lag", C.c_int32)]
+
+
+class AdamWGroup(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float)]
+
+
+class AdamWMulti(C.Structure):
+    _fields_ = [("descs", C.c_void_p), ("chunk_tensor", C.c_void_p), ("chunk_index", C.c_void_p),
+                ("n_chunks", C.c_int), ("groups", AdamWGroup * 8), ("step", C.c_int),
+                ("grad_sumsq", C.c_void_p), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float)]
+
+
 _lib = None
 
 
@@ -110,6 +126,7 @@ def lib():
         L.hero_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.hero_sumsq.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.hero_adamw.argtypes = [C.POINTER(AdamW), C.c_void_p]
+        L.hero_adamw_multi.argtypes = [C.POINTER(AdamWMulti), C.c_void_p]
         _lib = L
     return _lib
 

@@ -79,6 +79,13 @@ __device__ __forceinline__ void load_row_slice(const T* __restrict__ row, int p,
   }
 }
 
+// same, from an LDS matrix with row stride 64 (lanes sharing p read the same address -> broadcast)
+template <typename T, int DPL>
+__device__ __forceinline__ void lds_row_slice(const T* row, int p, float (&qv)[DPL]) {
+#pragma unroll
+  for (int t = 0; t < DPL; ++t) qv[t] = ld1<T>(row + p * DPL + t);
+}
+
 template <typename T, int LPK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,9 +96,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
   const int Lp = (L + 3) & ~3;
   T* Ks = reinterpret_cast<T*>(smem);
   T* Vs = Ks + (size_t)L * STR;
-  float* Ps = reinterpret_cast<float*>(smem + (((size_t)2 * L * STR * sizeof(T)) + 15) / 16 * 16) + wave * Lp;
+  T* Qs = Vs + (size_t)L * STR;
+  float* Ps = reinterpret_cast<float*>(smem + (((size_t)(2 * L * STR + L * DH) * sizeof(T)) + 15) / 16 * 16) + wave * Lp;
 
   const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D;
+  stage_head<T>(qkv + h * DH, 3 * D, L, Qs, DH);
   stage_head<T>(qkv + D + h * DH, 3 * D, L, Ks, STR);
   stage_head<T>(qkv + 2 * D + h * DH, 3 * D, L, Vs, STR);
   __syncthreads();
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
 
   for (int i = wave; i < L; i += 4) {
     float qv[DPL];
-    load_row_slice<T, DPL>(qkv + (size_t)i * 3 * D + h * DH, p, qv);
+    lds_row_slice<T, DPL>(Qs + i * DH, p, qv);
     // ---- scores
     float mx = -3.0e38f;
     for (int j0 = 0; j0 < L; j0 += KPP) {
@@ -160,6 +169,7 @@ template <typename T, int LPK, int KPW>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DPL = DH / LPK, KPP = 64 / LPK, STR = KvLay<T>::STRIDE;
+  constexpr int MAXP = LPK == 1 ? 4 : 1;   // score passes: L <= 256 (LPK 1), <= 32 (LPK 2), <= 16 (LPK 4)
   const int L = a.L, H = a.H, D = H * DH;
   const int s = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -190,34 +200,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
 
   for (int c0 = 0; c0 < L; c0 += R) {
     const int cr = min(R, L - c0);
+    // ---- stage this chunk's probability rows (contiguous cr*L floats) into Pd
+    {
+      const float* src = probs + (size_t)c0 * L;
+      for (int q = threadIdx.x; q < cr * L; q += blockDim.x) {
+        const int il = q / L, j = q - il * L;
+        Pd[(size_t)il * Lp + j] = src[q];
+      }
+    }
+    __syncthreads();
     // ---- phase A: rows of this chunk -> dS, Pd in LDS, dQ to HBM
     for (int il = wave; il < cr; il += 4) {
       const int i = c0 + il;
       float ov[DPL];
-      load_row_slice<T, DPL>(dctx + (size_t)i * D, p, ov);
+      lds_row_slice<T, DPL>(Os + i * DH, p, ov);
       float* dSr = dS + (size_t)il * Lp;
       float* Pdr = Pd + (size_t)il * Lp;
+      float prs[MAXP], dps[MAXP];
       float delta = 0.f;
-      for (int j0 = 0; j0 < L; j0 += KPP) {
-        const int j = j0 + g;
-        float dp = 0.f;
-        if (j < L) dp = Dot<T, DPL>::run(ov, Vs + j * STR + p * DPL);
 #pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) dp += __shfl_xor(dp, o, 64);
-        if (j < L && p == 0) {
-          const float pr = probs[(size_t)i * L + j];
-          const float m = drop.on() ? drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + j) : 1.f;
-          dp *= m;                 // dP_ij
-          Pdr[j] = pr * m;         // dropped probability (feeds dV)
-          dSr[j] = dp;             // temporarily dP
-          delta += dp * pr;
+      for (int ps = 0; ps < MAXP; ++ps) {
+        const int j = ps * KPP + g;
+        float dp = 0.f;
+        prs[ps] = 0.f;
+        if (ps * KPP < L) {
+          if (j < L) dp = Dot<T, DPL>::run(ov, Vs + j * STR + p * DPL);
+#pragma unroll
+          for (int o = 1; o < LPK; o <<= 1) dp += __shfl_xor(dp, o, 64);
+          if (j < L && p == 0) {
+            const float pr = Pdr[j];
+            const float m = drop.on() ? drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + j) : 1.f;
+            dp *= m;                 // dP_ij
+            Pdr[j] = pr * m;         // dropped probability (feeds dV)
+            prs[ps] = pr;
+            delta += dp * pr;
+          }
         }
+        dps[ps] = dp;
       }
       delta = wave_sum(delta);
-      wave_lds_sync();
-      for (int j = lane; j < L; j += 64) {
-        const float pr = probs[(size_t)i * L + j];
-        dSr[j] = pr * (dSr[j] - delta) * a.scale;
+#pragma unroll
+      for (int ps = 0; ps < MAXP; ++ps) {
+        const int j = ps * KPP + g;
+        if (ps * KPP < L && j < L && p == 0) dSr[j] = prs[ps] * (dps[ps] - delta) * a.scale;
       }
       wave_lds_sync();
       // dQ[i][lane] = sum_j dS_ij K[j][lane]
@@ -256,7 +281,7 @@ constexpr size_t LDS_BUDGET = 150 * 1024;
 
 template <typename T> static size_t fwd_lds(int L) {
   const int Lp = (L + 3) & ~3;
-  return (((size_t)2 * L * KvLay<T>::STRIDE * sizeof(T)) + 15) / 16 * 16 + (size_t)4 * Lp * sizeof(float);
+  return (((size_t)(2 * L * KvLay<T>::STRIDE + L * DH) * sizeof(T)) + 15) / 16 * 16 + (size_t)4 * Lp * sizeof(float);
 }
 template <typename T> static size_t bwd_lds_fixed(int L) {
   return (((size_t)(2 * L * KvLay<T>::STRIDE + 2 * L * DH) * sizeof(T)) + 15) / 16 * 16;

@@ -191,16 +191,34 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRed a) {
   }
 }
 
-__global__ void colred_final_kernel(const float* pg, const float* pb, float* og, float* ob, int cols, int nchunks, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[c] = beta*out[c] + sum_k partial[k][c]: 16 columns x 16 chunk-lanes per block, lanes of one
+// column combine with shuffles (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void colred_final_kernel(const float* pg, const float* pb, float* og, float* ob, int cols,
+                                                           int nchunks, float beta) {
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float sg = 0.f, sb = 0.f;
-  for (int k = 0; k < nchunks; ++k) {
-    if (og) sg += pg[(size_t)k * cols + c];
-    if (ob) sb += pb[(size_t)k * cols + c];
+  if (c < cols) {
+    for (int k = kl; k < nchunks; k += 16) {
+      if (og) sg += pg[(size_t)k * cols + c];
+      if (ob) sb += pb[(size_t)k * cols + c];
+    }
   }
-  if (og) og[c] = (beta != 0.f ? beta * og[c] : 0.f) + sg;
-  if (ob) ob[c] = (beta != 0.f ? beta * ob[c] : 0.f) + sb;
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    sg += __shfl_xor(sg, o, 64);
+    sb += __shfl_xor(sb, o, 64);
+  }
+  __shared__ float red[2][4][16];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 16) { red[0][wave][cl] = sg; red[1][wave][cl] = sb; }
+  __syncthreads();
+  if (threadIdx.x < 16 && c < cols) {
+    sg = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    sb = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if (og) og[c] = (beta != 0.f ? beta * og[c] : 0.f) + sg;
+    if (ob) ob[c] = (beta != 0.f ? beta * ob[c] : 0.f) + sb;
+  }
 }
 
 static inline int chunking(int rows, int* rpc) {
@@ -222,7 +240,7 @@ static int run_colred(const void* x, const void* dy, const float* mean, const fl
   hipLaunchKernelGGL((colred_kernel<TX, T>), dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, a);
   int rc = check_launch("colred");
   if (rc) return rc;
-  hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
+  hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
                      nchunks, beta);
   return check_launch("colred_final");
 }

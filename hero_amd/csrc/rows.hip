@@ -163,6 +163,66 @@ __global__ void adamw_kernel(HeroAdamW a, float bc1, float bc2) {
   }
 }
 
+// One launch over many tensors (descriptor tables live in device memory, one block per 16K-element
+// chunk).  Same arithmetic as adamw_kernel.
+constexpr int MT_CHUNK = 16384;
+__global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
+  const int ti = a.chunk_tensor[blockIdx.x];
+  const HeroTensorDesc d = a.descs[ti];
+  const HeroAdamWGroup gr = a.groups[d.group];
+  const size_t beg = (size_t)a.chunk_index[blockIdx.x] * MT_CHUNK;
+  const size_t end = beg + MT_CHUNK < d.n ? beg + MT_CHUNK : d.n;
+  float gs = a.grad_scale;
+  if (a.grad_sumsq) {
+    const float norm = sqrtf(*a.grad_sumsq) * fabsf(a.grad_scale);
+    const float clip = a.max_grad_norm / (norm + 1e-6f);
+    if (clip < 1.f) gs *= clip;
+  }
+  const float st = (float)(a.step - d.step_lag);
+  const float bc1 = 1.f - powf(gr.beta1, st), bc2 = 1.f - powf(gr.beta2, st);
+  const float step_size = gr.lr * sqrtf(bc2) / bc1;
+  const float decay = gr.lr * gr.weight_decay;
+  const bool vec = ((((uintptr_t)d.p | (uintptr_t)d.g | (uintptr_t)d.m | (uintptr_t)d.v) & 15) == 0);
+  if (vec) {
+    const size_t e4 = beg + ((end - beg) & ~(size_t)3);
+    for (size_t i = beg + threadIdx.x * 4; i < e4; i += 256 * 4) {
+      float4 p = *reinterpret_cast<float4*>(d.p + i);
+      const float4 g4 = *reinterpret_cast<const float4*>(d.g + i);
+      float4 m = *reinterpret_cast<float4*>(d.m + i);
+      float4 v = *reinterpret_cast<float4*>(d.v + i);
+      float* pp = &p.x; const float* gp = &g4.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float g = gp[k] * gs;
+        mp[k] = gr.beta1 * mp[k] + (1.f - gr.beta1) * g;
+        vp[k] = gr.beta2 * vp[k] + (1.f - gr.beta2) * g * g;
+        pp[k] -= step_size * mp[k] / (sqrtf(vp[k]) + gr.eps);
+        pp[k] -= decay * pp[k];
+      }
+      *reinterpret_cast<float4*>(d.p + i) = p;
+      *reinterpret_cast<float4*>(d.m + i) = m;
+      *reinterpret_cast<float4*>(d.v + i) = v;
+    }
+    for (size_t i = e4 + threadIdx.x; i < end; i += 256) {
+      const float g = d.g[i] * gs;
+      const float m = gr.beta1 * d.m[i] + (1.f - gr.beta1) * g;
+      const float v = gr.beta2 * d.v[i] + (1.f - gr.beta2) * g * g;
+      float p = d.p[i] - step_size * m / (sqrtf(v) + gr.eps);
+      p -= decay * p;
+      d.p[i] = p; d.m[i] = m; d.v[i] = v;
+    }
+  } else {
+    for (size_t i = beg + threadIdx.x; i < end; i += 256) {
+      const float g = d.g[i] * gs;
+      const float m = gr.beta1 * d.m[i] + (1.f - gr.beta1) * g;
+      const float v = gr.beta2 * d.v[i] + (1.f - gr.beta2) * g * g;
+      float p = d.p[i] - step_size * m / (sqrtf(v) + gr.eps);
+      p -= decay * p;
+      d.p[i] = p; d.m[i] = m; d.v[i] = v;
+    }
+  }
+}
+
 static inline int grid_for(size_t work_items) {
   size_t b = (work_items + 255) / 256;
   if (b < 1) b = 1;
@@ -289,3 +349,12 @@ extern "C" int hero_adamw(const HeroAdamW* a, hero_stream_t stream) {
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(a->n >> 2)), dim3(256), 0, s, *a, bc1, bc2);
   return check_launch("hero_adamw");
 }
+
+extern "C" int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream) {
+  HERO_REQUIRE(a && a->descs && a->chunk_tensor && a->chunk_index, "hero_adamw_multi: null pointer");
+  HERO_REQUIRE(a->step >= 1, "hero_adamw_multi: step must be >= 1");
+  if (a->n_chunks <= 0) return HERO_OK;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(a->n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  return check_launch("hero_adamw_multi");
+}
+extern "C" int hero_adamw_multi_chunk(void) { return MT_CHUNK; }

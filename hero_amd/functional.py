@@ -125,13 +125,61 @@ def packed(params, dtype):
 
 
 # --------------------------------------------------------------------------------------------- #
+# parameter-gradient sink
+# --------------------------------------------------------------------------------------------- #
+class GradSink:
+    """Where the HIP backward kernels ACCUMULATE parameter gradients (dW += ..., fp32).
+
+    The kernels add straight into `p.grad` (allocated zeroed on first use), so there are no
+    per-parameter temporaries and no autograd AccumulateGrad launches; the functions return None
+    for parameter inputs.  hero_amd.utils.distributed.GradArena subclasses this to make every
+    `p.grad` a view of one flat buffer and to launch bucketed all-reduces as gradients become
+    final (`use` is called once per forward use of a parameter, `done` once per backward use)."""
+
+    def dst(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return p.grad
+
+    def use(self, p):
+        pass
+
+    def done(self, p):
+        pass
+
+
+SINK = GradSink()
+
+
+def set_grad_sink(sink):
+    global SINK
+    SINK = sink if sink is not None else GradSink()
+
+
+def _use(*params):
+    if torch.is_grad_enabled():
+        for p in params:
+            if p is not None and p.requires_grad:
+                SINK.use(p)
+
+
+def _is_param(t):
+    return t is not None and t.is_leaf and t.requires_grad
+
+
+# --------------------------------------------------------------------------------------------- #
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------- #
+def _p(t):
+    return t if isinstance(t, int) else L.ptr(t)
+
+
 def k_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, al, bl, dtype_code, bias=None, residual=None,
            aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None):
-    epi = L.GemmEpilogue(L.ptr(bias), L.ptr(residual), L.ptr(aux), act, 1 if out_f32 else 0,
+    """A/B/Cm may be tensors or raw device pointers (int) for column-sliced operands."""
+    epi = L.GemmEpilogue(_p(bias), _p(residual), _p(aux), act, 1 if out_f32 else 0,
                          beta, split_k, _d(drop))
-    L.check(L.lib().hero_gemm(L.ptr(A), L.ptr(B), L.ptr(Cm), M, N, K, lda, ldb, ldc, al, bl,
+    L.check(L.lib().hero_gemm(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, al, bl,
                               dtype_code, C.byref(epi), L.stream()))
 
 
@@ -162,24 +210,52 @@ def _split_for(n_out, n_in, rows, bk):
     return max(1, min(split, ktiles // 4))
 
 
-def k_wgrad(dy2, x2):
-    """dW[N,K] (fp32) = dy2[M,N]^T @ x2[M,K]."""
-    M, N = dy2.shape
+def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None):
+    """dW[N,K] (fp32) = beta*dW + dy2[:, col0:col0+N]^T @ x2[M,K]."""
+    M, ld = dy2.shape
+    N = ld - col0 if ncols is None else ncols
     K = x2.shape[1]
-    dW = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
     split = _split_for(N, K, M, 64 if dy2.dtype == torch.bfloat16 else 32)
-    k_gemm(dy2, x2, dW, N, K, M, N, K, K, L.LAYOUT_O, L.LAYOUT_O, L.dt(dy2), out_f32=True,
-           beta=0.0, split_k=split)
-    return dW
-
-
-def k_colsum(dy2):
-    M, N = dy2.shape
-    out = torch.empty((N,), dtype=torch.float32, device=dy2.device)
-    ws = torch.empty((256 * N,), dtype=torch.float32, device=dy2.device)
-    L.check(L.lib().hero_colsum(L.ptr(dy2), L.ptr(out), M, N, N, L.dt(dy2), 0.0, L.ptr(ws),
-                                L.stream()))
+    a = L.ptr(dy2) + col0 * dy2.element_size()
+    k_gemm(a, x2, out, N, K, M, ld, K, K, L.LAYOUT_O, L.LAYOUT_O, L.dt(dy2), out_f32=True,
+           beta=beta, split_k=split)
     return out
+
+
+_WS = {}
+
+
+def _workspace(n_floats, device):
+    key = (device.type, device.index)
+    t = _WS.get(key)
+    if t is None or t.numel() < n_floats:
+        t = torch.empty((max(n_floats, 1 << 20),), dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
+def k_colsum(dy2, out=None, beta=0.0, col0=0, ncols=None):
+    M, ld = dy2.shape
+    N = ld - col0 if ncols is None else ncols
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=dy2.device)
+    ws = _workspace(256 * N, dy2.device)      # stream-ordered reuse
+    L.check(L.lib().hero_colsum(L.ptr(dy2) + col0 * dy2.element_size(), L.ptr(out), M, N, ld,
+                                L.dt(dy2), beta, L.ptr(ws), L.stream()))
+    return out
+
+
+def acc_linear_grads(dy2, x2, weight, bias, col0=0):
+    """weight.grad += dy^T x ; bias.grad += colsum(dy) straight into the gradient sink."""
+    N = weight.shape[0]
+    if weight.requires_grad:
+        k_wgrad(dy2, x2, out=SINK.dst(weight), beta=1.0, col0=col0, ncols=N)
+        SINK.done(weight)
+    if bias is not None and bias.requires_grad:
+        k_colsum(dy2, out=SINK.dst(bias), beta=1.0, col0=col0, ncols=N)
+        SINK.done(bias)
 
 
 def k_ln_fwd(x2, gamma, beta, eps, out_dtype, rows, cols, tabs=(), idxs=(), want_pre=False,
@@ -204,19 +280,36 @@ def k_ln_fwd(x2, gamma, beta, eps, out_dtype, rows, cols, tabs=(), idxs=(), want
     return y, mean, rstd, pre
 
 
+def ln_param_dsts(gamma_p, beta_p):
+    """(dgamma dst, dbeta dst) in the gradient sink for LayerNorm parameters (None if frozen)."""
+    dg = SINK.dst(gamma_p) if gamma_p.requires_grad else None
+    db = SINK.dst(beta_p) if beta_p.requires_grad else None
+    return dg, db
+
+
+def ln_params_done(gamma_p, beta_p):
+    if gamma_p.requires_grad:
+        SINK.done(gamma_p)
+    if beta_p.requires_grad:
+        SINK.done(beta_p)
+
+
 def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_out=None,
-             drop_in=None):
+             drop_in=None, dgamma=None, dbeta=None, grad_beta=0.0):
+    """dgamma/dbeta given: accumulate into them with grad_beta (the gradient sink path)."""
     rows, cols = dy2.shape
     dev = dy2.device
     dx = torch.empty_like(dy2) if want_dx else None
     dxd = torch.empty_like(dy2) if (want_dx and drop_in is not None) else None
-    dg = torch.empty((cols,), dtype=torch.float32, device=dev) if want_params else None
-    db = torch.empty((cols,), dtype=torch.float32, device=dev) if want_params else None
-    ws = torch.empty((512 * cols,), dtype=torch.float32, device=dev) if want_params else None
+    dg, db = dgamma, dbeta
+    if want_params and dg is None and db is None:
+        dg = torch.empty((cols,), dtype=torch.float32, device=dev)
+        db = torch.empty((cols,), dtype=torch.float32, device=dev)
+    ws = _workspace(512 * cols, dev) if (dg is not None or db is not None) else None
     a = L.LnBwd()
     a.x, a.dy, a.gamma, a.mean, a.rstd = L.ptr(x2), L.ptr(dy2), L.ptr(gamma), L.ptr(mean), L.ptr(rstd)
     a.dx, a.dx_dropped, a.dgamma, a.dbeta = L.ptr(dx), L.ptr(dxd), L.ptr(dg), L.ptr(db)
-    a.grad_beta, a.workspace = 0.0, L.ptr(ws)
+    a.grad_beta, a.workspace = grad_beta, L.ptr(ws)
     a.rows, a.cols, a.x_dtype, a.dtype = rows, cols, L.dt(x2), L.dt(dy2)
     a.dropout_out, a.dropout_in = _d(drop_out), _d(drop_in)
     L.check(L.lib().hero_layernorm_bwd(C.byref(a), L.stream()))
@@ -309,7 +402,8 @@ def cast(x, dtype):
 
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) [+ residual]; act in {none, relu, gelu}.  (nn.Linear call sites outside
-    the fused blocks: img_linear, frame_transform, query_input_proj, standalone sub-modules.)"""
+    the fused blocks: img_linear, frame_transform, query_input_proj, standalone sub-modules.)
+    Leaf-parameter gradients go to the gradient sink; other weight tensors get normal gradients."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, residual):
@@ -323,20 +417,27 @@ class LinearFn(torch.autograd.Function):
         ctx.act = act
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
+        ctx.params = (weight, bias)
+        ctx.sink = _is_param(weight) and (bias is None or _is_param(bias))
+        if ctx.sink:
+            _use(weight, bias)
         ctx.save_for_backward(x2, Wc, aux)
-        ctx.has_bias = bias is not None
         return y.view(*x.shape[:-1], Wc.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, Wc, aux = ctx.saved_tensors
+        weight, bias = ctx.params
         dy2 = _as2d(dy)
         dz = dy2 if ctx.act == L.ACT_NONE else k_act_bwd(dy2, aux, ctx.act)
         dx = k_dgrad(dz, Wc).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dW = k_wgrad(dz, x2) if ctx.needs_input_grad[1] else None
-        db = k_colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        dres = dy if ctx.has_res else None
-        return dx, dW, db, None, dres
+        dW = db = None
+        if ctx.sink:
+            acc_linear_grads(dz, x2, weight, bias)
+        else:
+            dW = k_wgrad(dz, x2) if ctx.needs_input_grad[1] else None
+            db = k_colsum(dz) if (bias is not None and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, None, (dy if ctx.has_res else None)
 
 
 def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None):
@@ -345,7 +446,8 @@ def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None):
 
 class EmbedLnFn(torch.autograd.Function):
     """y = dropout(LN(x + sum_k table_k[idx_k])) — embedding sums of model/embed.py fused with their
-    LayerNorm.  idx_k None = row 0 of the given (fp32) table slice for every row."""
+    LayerNorm.  idx_k None = row 0 of the given (fp32) table slice for every row.  Gradients of
+    leaf tables are scatter-added straight into the gradient sink (no dense temporary)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, drop, out_dtype, skip_idx, idxs, *tables):
@@ -357,7 +459,12 @@ class EmbedLnFn(torch.autograd.Function):
                                       tabs=tabs, idxs=idxs, want_pre=len(tables) > 0, drop=drop,
                                       device=gamma.device)
         ctx.drop, ctx.idxs, ctx.skip = drop, idxs, skip_idx
-        ctx.tab_shapes = [t.shape for t in tables]
+        ctx.tables = tables
+        ctx.ln = (gamma, beta)
+        ctx.ln_sink = _is_param(gamma) and _is_param(beta)
+        _use(*[t for t in tables if _is_param(t)])
+        if ctx.ln_sink:
+            _use(gamma, beta)
         ctx.has_x = x is not None
         ctx.xshape = x.shape if x is not None else None
         ctx.save_for_backward(pre if pre is not None else x2, gamma.detach(), mean, rstd)
@@ -367,20 +474,36 @@ class EmbedLnFn(torch.autograd.Function):
     def backward(ctx, dy):
         pre, gamma, mean, rstd = ctx.saved_tensors
         dy2 = _as2d(dy)
-        want_dx = (ctx.has_x and ctx.needs_input_grad[0]) or len(ctx.tab_shapes) > 0
-        dx, _, dg, db = k_ln_bwd(pre, dy2, gamma, mean, rstd, want_dx=want_dx, drop_out=ctx.drop)
+        gp, bp = ctx.ln
+        want_dx = (ctx.has_x and ctx.needs_input_grad[0]) or len(ctx.tables) > 0
+        if ctx.ln_sink:
+            dgd, dbd = ln_param_dsts(gp, bp)
+            dx, _, _, _ = k_ln_bwd(pre, dy2, gamma, mean, rstd, want_dx=want_dx, drop_out=ctx.drop,
+                                   dgamma=dgd, dbeta=dbd, grad_beta=1.0, want_params=False)
+            ln_params_done(gp, bp)
+            dg = db = None
+        else:
+            dx, _, dg, db = k_ln_bwd(pre, dy2, gamma, mean, rstd, want_dx=want_dx, drop_out=ctx.drop)
         grads_t = []
-        for k, shp in enumerate(ctx.tab_shapes):
-            if not ctx.needs_input_grad[8 + k]:
-                grads_t.append(None)
-                continue
-            g = torch.zeros(shp, dtype=torch.float32, device=dy.device)
+        for k, tab in enumerate(ctx.tables):
             idx = ctx.idxs[k] if k < len(ctx.idxs) else None
-            if idx is None:
-                g.view(-1, shp[-1])[0].copy_(k_colsum(dx))
+            skip = ctx.skip[k] if ctx.skip else -1
+            if _is_param(tab):
+                if idx is None:
+                    k_colsum(dx, out=SINK.dst(tab).view(-1, tab.shape[-1])[0], beta=1.0)
+                else:
+                    k_scatter_add(dx, idx, SINK.dst(tab), None, skip)
+                SINK.done(tab)
+                grads_t.append(None)
+            elif not ctx.needs_input_grad[8 + k]:
+                grads_t.append(None)
             else:
-                k_scatter_add(dx, idx, g, None, ctx.skip[k] if ctx.skip else -1)
-            grads_t.append(g)
+                g = torch.zeros(tab.shape, dtype=torch.float32, device=dy.device)
+                if idx is None:
+                    k_colsum(dx, out=g.view(-1, tab.shape[-1])[0])
+                else:
+                    k_scatter_add(dx, idx, g, None, skip)
+                grads_t.append(g)
         gx = dx.view(ctx.xshape) if (ctx.has_x and ctx.needs_input_grad[0]) else None
         return (gx, dg, db, None, None, None, None, None) + tuple(grads_t)
 
@@ -432,10 +555,13 @@ class CsrGatherSumFn(torch.autograd.Function):
 
 
 # ---- transformer blocks ------------------------------------------------------------------------
-def _attn_fwd_core(x2, S, Lq, H, mask_add, Wqkv, bqkv, p_attn_drop):
-    qkv = k_linear(x2, Wqkv, bqkv)
-    ctxt, probs = k_attn_fwd(qkv, mask_add, S, Lq, H, drop=p_attn_drop)
-    return qkv, ctxt, probs
+# Parameters of the blocks are always leaf nn.Parameters; their gradients go to the gradient sink
+# (accumulated in place by the kernels) and the functions return None for them.
+def _qkv_bwd(dqkv, x2, qkv_params, D):
+    wq, bq, wk, bk, wv, bv = qkv_params
+    acc_linear_grads(dqkv, x2, wq, bq, col0=0)
+    acc_linear_grads(dqkv, x2, wk, bk, col0=D)
+    acc_linear_grads(dqkv, x2, wv, bv, col0=2 * D)
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -447,8 +573,11 @@ class SelfAttentionFn(torch.autograd.Function):
         x2 = _as2d(x)
         Wqkv = packed((wq, wk, wv), x2.dtype)
         bqkv = packed((bq, bk, bv), torch.float32)
-        qkv, ctxt, probs = _attn_fwd_core(x2, S, Lq, H, mask_add, Wqkv, bqkv, drop_p)
+        qkv = k_linear(x2, Wqkv, bqkv)
+        ctxt, probs = k_attn_fwd(qkv, mask_add, S, Lq, H, drop=drop_p)
         ctx.dims, ctx.drop = (S, Lq, H, D), drop_p
+        ctx.params = (wq, bq, wk, bk, wv, bv)
+        _use(*ctx.params)
         ctx.save_for_backward(x2, Wqkv, qkv, probs)
         return ctxt.view(S, Lq, D)
 
@@ -457,10 +586,9 @@ class SelfAttentionFn(torch.autograd.Function):
         x2, Wqkv, qkv, probs = ctx.saved_tensors
         S, Lq, H, D = ctx.dims
         dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop)
-        dx = k_dgrad(dqkv, Wqkv).view(S, Lq, D)
-        dW = k_wgrad(dqkv, x2)
-        db = k_colsum(dqkv)
-        return (dx, None, None, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D], dW[2 * D:], db[2 * D:])
+        dx = k_dgrad(dqkv, Wqkv).view(S, Lq, D) if ctx.needs_input_grad[0] else None
+        _qkv_bwd(dqkv, x2, ctx.params, D)
+        return (dx,) + (None,) * 9
 
 
 class ProjResLnFn(torch.autograd.Function):
@@ -474,15 +602,22 @@ class ProjResLnFn(torch.autograd.Function):
         out, mean, rstd, _ = k_ln_fwd(y, gamma.detach(), beta.detach(), eps, y.dtype, y.shape[0], y.shape[1])
         ctx.drop = drop
         ctx.hshape, ctx.rshape = h.shape, res.shape
+        ctx.params = (w, b, gamma, beta)
+        _use(*ctx.params)
         ctx.save_for_backward(h2, Wc, y, mean, rstd, gamma.detach())
         return out.view(res.shape)
 
     @staticmethod
     def backward(ctx, dout):
         h2, Wc, y, mean, rstd, gamma = ctx.saved_tensors
-        dy, dyd, dg, dbt = k_ln_bwd(y, _as2d(dout), gamma, mean, rstd, drop_in=ctx.drop)
+        w, b, gp, bp = ctx.params
+        dgd, dbd = ln_param_dsts(gp, bp)
+        dy, dyd, _, _ = k_ln_bwd(y, _as2d(dout), gamma, mean, rstd, drop_in=ctx.drop, dgamma=dgd,
+                                 dbeta=dbd, grad_beta=1.0, want_params=False)
+        ln_params_done(gp, bp)
+        acc_linear_grads(dyd, h2, w, b)
         dh = k_dgrad(dyd, Wc).view(ctx.hshape)
-        return dh, dy.view(ctx.rshape), None, None, k_wgrad(dyd, h2), k_colsum(dyd), dg, dbt
+        return (dh, dy.view(ctx.rshape)) + (None,) * 6
 
 
 class AttnBlockFn(torch.autograd.Function):
@@ -495,10 +630,13 @@ class AttnBlockFn(torch.autograd.Function):
         Wqkv = packed((wq, wk, wv), x2.dtype)
         bqkv = packed((bq, bk, bv), torch.float32)
         Wo = packed((wo,), x2.dtype)
-        qkv, ctxt, probs = _attn_fwd_core(x2, S, Lq, H, mask_add, Wqkv, bqkv, drop_attn)
+        qkv = k_linear(x2, Wqkv, bqkv)
+        ctxt, probs = k_attn_fwd(qkv, mask_add, S, Lq, H, drop=drop_attn)
         y1 = k_linear(ctxt, Wo, bo.detach(), residual=x2, drop=drop_hid)
         a, mean, rstd, _ = k_ln_fwd(y1, g1.detach(), b1.detach(), eps, y1.dtype, S * Lq, D)
         ctx.dims, ctx.drops = (S, Lq, H, D), (drop_attn, drop_hid)
+        ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1)
+        _use(*ctx.params)
         ctx.save_for_backward(x2, Wqkv, Wo, qkv, probs, ctxt, y1, mean, rstd, g1.detach())
         return a.view(S, Lq, D)
 
@@ -507,16 +645,17 @@ class AttnBlockFn(torch.autograd.Function):
         x2, Wqkv, Wo, qkv, probs, ctxt, y1, mean, rstd, g1 = ctx.saved_tensors
         S, Lq, H, D = ctx.dims
         drop_attn, drop_hid = ctx.drops
-        dy1, dy1d, dg1, db1 = k_ln_bwd(y1, _as2d(da), g1, mean, rstd, drop_in=drop_hid)
-        dbo = k_colsum(dy1d)
-        dWo = k_wgrad(dy1d, ctxt)
+        wq, bq, wk, bk, wv, bv, wo, bo, g1p, b1p = ctx.params
+        dgd, dbd = ln_param_dsts(g1p, b1p)
+        dy1, dy1d, _, _ = k_ln_bwd(y1, _as2d(da), g1, mean, rstd, drop_in=drop_hid, dgamma=dgd,
+                                   dbeta=dbd, grad_beta=1.0, want_params=False)
+        ln_params_done(g1p, b1p)
+        acc_linear_grads(dy1d, ctxt, wo, bo)
         dctx = k_dgrad(dy1d, Wo)
         dqkv = k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=drop_attn)
-        dW = k_wgrad(dqkv, x2)
-        db = k_colsum(dqkv)
+        _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
         dx = k_dgrad(dqkv, Wqkv, residual=dy1).view(S, Lq, D)      # + residual-path gradient, fused
-        return (dx, None, None, None, None, None, dW[:D], db[:D], dW[D:2 * D], db[D:2 * D],
-                dW[2 * D:], db[2 * D:], dWo, dbo, dg1, db1)
+        return (dx,) + (None,) * 15
 
 
 class FfnBlockFn(torch.autograd.Function):
@@ -533,17 +672,21 @@ class FfnBlockFn(torch.autograd.Function):
         y2 = k_linear(hg, W2, b2.detach(), residual=a2, drop=drop_hid)
         out, mean, rstd, _ = k_ln_fwd(y2, g2.detach(), bt2.detach(), eps, y2.dtype, y2.shape[0], y2.shape[1])
         ctx.drop, ctx.shp = drop_hid, shp
+        ctx.params = (w1, b1, w2, b2, g2, bt2)
+        _use(*ctx.params)
         ctx.save_for_backward(a2, W1, W2, u, hg, y2, mean, rstd, g2.detach())
         return out.view(shp)
 
     @staticmethod
     def backward(ctx, dout):
         a2, W1, W2, u, hg, y2, mean, rstd, g2 = ctx.saved_tensors
-        dy2, dy2d, dg2, dbt2 = k_ln_bwd(y2, _as2d(dout), g2, mean, rstd, drop_in=ctx.drop)
-        db2 = k_colsum(dy2d)
-        dW2 = k_wgrad(dy2d, hg)
+        w1, b1, w2, b2, g2p, bt2p = ctx.params
+        dgd, dbd = ln_param_dsts(g2p, bt2p)
+        dy2, dy2d, _, _ = k_ln_bwd(y2, _as2d(dout), g2, mean, rstd, drop_in=ctx.drop, dgamma=dgd,
+                                   dbeta=dbd, grad_beta=1.0, want_params=False)
+        ln_params_done(g2p, bt2p)
+        acc_linear_grads(dy2d, hg, w2, b2)
         du = k_dgrad(dy2d, W2, act=L.ACT_GELU_BWD, aux=u)           # * gelu'(u), fused
-        db1 = k_colsum(du)
-        dW1 = k_wgrad(du, a2)
+        acc_linear_grads(du, a2, w1, b1)
         da = k_dgrad(du, W1, residual=dy2).view(ctx.shp)            # + residual-path gradient, fused
-        return da, None, None, dW1, db1, dW2, db2, dg2, dbt2
+        return (da,) + (None,) * 8

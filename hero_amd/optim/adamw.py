@@ -1,9 +1,12 @@
-"""AdamW with the reference's update rule (optim/adamw.py:43-106) as ONE HIP kernel per tensor:
-bias-corrected Adam step, then decoupled decay p -= lr * wd * p, eps = 1e-6 added to sqrt(v).
-Gradient-norm clipping (train_vcmr.py:257-260) and the 1/world_size averaging can be folded into
-the same pass (`step(grad_sumsq=..., max_grad_norm=..., grad_scale=...)`)."""
+"""AdamW with the reference's update rule (optim/adamw.py:43-106): bias-corrected Adam step, then
+decoupled decay p -= lr * wd * p, eps = 1e-6 added to sqrt(v) — as ONE multi-tensor HIP launch
+per optimiser step (hero_adamw_multi).  Gradient-norm clipping (train_vcmr.py:257-260) and the
+1/world_size averaging fold into the same pass (`step(grad_sumsq=..., max_grad_norm=...,
+grad_scale=...)`).  Parameters whose .grad is None (or listed in `skip`) are left untouched, state
+included, exactly like the reference's `if p.grad is None: continue`."""
 import ctypes as C
 
+import numpy as np
 import torch
 from torch.optim import Optimizer
 
@@ -20,15 +23,19 @@ class AdamW(Optimizer):
             raise NotImplementedError("correct_bias=False is not used by HERO")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       correct_bias=correct_bias))
+        if len(self.param_groups) > 8:
+            raise ValueError("hero_amd AdamW supports up to 8 parameter groups")
+        self._global_step = 0
+        self._table = None        # (signature, device tensors, n_chunks)
 
-    def grad_sumsq(self):
-        """Device scalar = sum of squared gradients over all parameters (for clipping)."""
-        dev = self.param_groups[0]["params"][0].device if self.param_groups[0]["params"] else None
-        for g in self.param_groups:
-            for p in g["params"]:
-                dev = p.device
-                break
+    # ---- gradient norm ---------------------------------------------------------------------------
+    def grad_sumsq(self, flat=None):
+        """Device scalar = sum of squared gradients (one launch over a flat arena if given)."""
+        dev = next(p for g in self.param_groups for p in g["params"]).device
         out = torch.zeros(1, dtype=torch.float32, device=dev)
+        if flat is not None:
+            L.check(L.lib().hero_sumsq(L.ptr(flat), flat.numel(), L.ptr(out), L.stream()))
+            return out
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is not None:
@@ -36,11 +43,33 @@ class AdamW(Optimizer):
                     L.check(L.lib().hero_sumsq(L.ptr(gr), gr.numel(), L.ptr(out), L.stream()))
         return out
 
+    # ---- descriptor table ------------------------------------------------------------------------
+    def _build_table(self, active):
+        chunk = L.lib().hero_adamw_multi_chunk()
+        descs = (L.TensorDesc * len(active))()
+        ct, ci = [], []
+        for i, (gi, p) in enumerate(active):
+            st = self.state[p]
+            g = p.grad
+            if not (p.is_contiguous() and g.is_contiguous()):
+                raise RuntimeError("hero_amd AdamW needs contiguous parameters and gradients")
+            descs[i] = L.TensorDesc(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                    p.numel(), gi, self._global_step - st["step"])
+            n = -(-p.numel() // chunk)
+            ct.extend([i] * n)
+            ci.extend(range(n))
+        dev = active[0][1].device
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        t_ct = torch.from_numpy(np.asarray(ct, dtype=np.int32)).to(dev)
+        t_ci = torch.from_numpy(np.asarray(ci, dtype=np.int32)).to(dev)
+        return raw, t_ct, t_ci, len(ct)
+
     @torch.no_grad()
     def step(self, closure=None, grad_sumsq=None, max_grad_norm=0.0, grad_scale=1.0, skip=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
+        self._global_step += 1
+        active = []
+        for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None or (skip is not None and p in skip):
                     continue
@@ -50,10 +79,22 @@ class AdamW(Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                a = L.AdamW(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                            p.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"],
-                            st["step"], L.ptr(grad_sumsq), max_grad_norm, grad_scale, None)
-                L.check(L.lib().hero_adamw(C.byref(a), L.stream()))
+                active.append((gi, p))
+        if not active:
+            return loss
+        sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self._global_step - self.state[p]["step"])
+                    for _, p in active)
+        if self._table is None or self._table[0] != sig:
+            self._table = (sig,) + self._build_table(active)
+        _, raw, t_ct, t_ci, n_chunks = self._table
+        a = L.AdamWMulti()
+        a.descs, a.chunk_tensor, a.chunk_index, a.n_chunks = raw.data_ptr(), t_ct.data_ptr(), t_ci.data_ptr(), n_chunks
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            a.groups[gi] = L.AdamWGroup(group["lr"], b1, b2, group["eps"], group["weight_decay"])
+        a.step = self._global_step
+        a.grad_sumsq = L.ptr(grad_sumsq)
+        a.max_grad_norm, a.grad_scale = max_grad_norm, grad_scale
+        L.check(L.lib().hero_adamw_multi(C.byref(a), L.stream()))
         HF.notify_weights_updated()
         return loss

@@ -50,7 +50,7 @@ class TrainStep:
             for g in self.optimizer.param_groups:
                 g["lr"] = lr                       # train_vcmr.py:248-249 (all groups)
             untouched = [p for p in self.arena.params if p not in self.arena.touched]
-            sumsq = self.optimizer.grad_sumsq() if self.opts.grad_norm != -1 else None
+            sumsq = self.optimizer.grad_sumsq(self.arena.flat) if self.opts.grad_norm != -1 else None
             self.optimizer.step(grad_sumsq=sumsq, max_grad_norm=float(self.opts.grad_norm),
                                 grad_scale=1.0 / D.world_size(), skip=set(untouched))
             self.arena.zero()

@@ -16,6 +16,8 @@ import pickle
 import torch
 import torch.distributed as dist
 
+from .. import functional as HF
+
 
 def _on():
     return dist.is_available() and dist.is_initialized()
@@ -76,18 +78,22 @@ def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
     flush()
 
 
-class GradArena:
+class GradArena(HF.GradSink):
     """Flat fp32 gradient arena with bucketed, backward-overlapped all-reduce.
 
-    `p.grad` of every parameter is a view into one buffer; autograd accumulates into it in
-    place.  Buckets are cut in reverse parameter order (~ the order gradients become final) and a
-    bucket's all-reduce is issued asynchronously the moment its last gradient has been
-    accumulated (post-accumulate-grad hooks); `finish()` issues the leftovers and waits.
+    `p.grad` of every parameter is a view into ONE buffer.  The HIP backward kernels accumulate
+    into it directly (this object is installed as hero_amd.functional's gradient sink); the few
+    parameters that go through stock autograd (task-head ops) accumulate in place through
+    AccumulateGrad.  Buckets are cut in reverse parameter order (~ the order gradients become
+    final); a bucket's all-reduce is issued asynchronously the moment its last gradient is final,
+    while the rest of backward is still running; `finish()` issues the leftovers and waits.
+    A parameter used several times in one forward (the cross-modal encoder runs on subtitles AND
+    on queries) is final when its last pending use has been back-propagated (`use`/`done`).
     The 1/world_size factor is NOT applied here: hand `grad_scale = 1/world_size` to the fused
-    optimiser (hero_amd.optim.AdamW) or call `scale_()`.
+    optimiser or call `scale_()`.
     """
 
-    def __init__(self, params, bucket_bytes=64 << 20, overlap=True):
+    def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -98,8 +104,9 @@ class GradArena:
         off, start, count = 0, 0, 0
         for p in reversed(self.params):
             n = p.numel()
+            pad = (-off) % 4                 # keep every slice 16-byte aligned for the kernels
+            off += pad
             self.slices[p] = (off, off + n)
-            p.grad = self.flat[off:off + n].view_as(p)
             self.bucket_of[p] = len(self.buckets)
             off += n
             count += 1
@@ -108,22 +115,56 @@ class GradArena:
                 start, count = off, 0
         if count:
             self.buckets.append([start, off, count])
+        if off > total:
+            self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p in self.params:
+            s, e = self.slices[p]
+            p.grad = self.flat[s:e].view_as(p)
         self.sync = True
         self.overlap = overlap
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._final = set()
+        self._uses = {}
         self._handles = []
         self.touched = set()
         for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+            p.register_post_accumulate_grad_hook(self._autograd_hook)
+        if install:
+            HF.set_grad_sink(self)
 
-    def _hook(self, p):
-        self.touched.add(p)
-        if p.grad.data_ptr() != self.flat.data_ptr() + self.slices[p][0] * 4:
+    # ---- GradSink interface (HIP kernels) --------------------------------------------------------
+    def dst(self, p):
+        sl = self.slices.get(p)
+        if sl is None:
+            return super().dst(p)
+        if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + sl[0] * 4:
+            p.grad = self.flat[sl[0]:sl[1]].view_as(p)
+        return p.grad
+
+    def use(self, p):
+        self._uses[p] = self._uses.get(p, 0) + 1
+
+    def done(self, p):
+        n = self._uses.get(p, 1) - 1
+        self._uses[p] = n
+        if n <= 0:
+            self._on_final(p)
+
+    # ---- stock autograd path -----------------------------------------------------------------------
+    def _autograd_hook(self, p):
+        sl = self.slices[p]
+        if p.grad.data_ptr() != self.flat.data_ptr() + sl[0] * 4:
             # something replaced .grad (e.g. zero_grad(set_to_none=True)); fold it back
-            s, e = self.slices[p]
-            self.flat[s:e].add_(p.grad.reshape(-1))
-            p.grad = self.flat[s:e].view_as(p)
+            self.flat[sl[0]:sl[1]].add_(p.grad.reshape(-1))
+            p.grad = self.flat[sl[0]:sl[1]].view_as(p)
+        self._on_final(p)
+
+    def _on_final(self, p):
+        self.touched.add(p)
+        if p in self._final or p not in self.bucket_of:
+            return
+        self._final.add(p)
         if not (self.sync and self.overlap) or world_size() == 1:
             return
         b = self.bucket_of[p]
@@ -152,6 +193,8 @@ class GradArena:
         self._handles = []
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._final.clear()
+        self._uses.clear()
 
     def scale_(self, factor):
         self.flat.mul_(factor)

@@ -208,6 +208,37 @@ typedef struct HeroAdamW {
 } HeroAdamW;
 int hero_adamw(const HeroAdamW* a, hero_stream_t stream);
 
+/* Multi-tensor form: ONE launch updates every tensor in a device-resident descriptor table (one
+ * workgroup per hero_adamw_multi_chunk()-element chunk). `chunk_tensor[c]` is the descriptor a chunk
+ * belongs to, `chunk_index[c]` its index within that tensor. A tensor's own step count is
+ * step - step_lag (parameters that received no gradient in some steps lag behind, as with the
+ * reference's per-parameter state['step']). */
+typedef struct HeroTensorDesc {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  uint64_t n;
+  int32_t group;
+  int32_t step_lag;
+} HeroTensorDesc;
+typedef struct HeroAdamWGroup {
+  float lr, beta1, beta2, eps, weight_decay;
+} HeroAdamWGroup;
+typedef struct HeroAdamWMulti {
+  const HeroTensorDesc* descs; /* device */
+  const int32_t* chunk_tensor; /* device [n_chunks] */
+  const int32_t* chunk_index;  /* device [n_chunks] */
+  int n_chunks;
+  HeroAdamWGroup groups[8];
+  int step;
+  const float* grad_sumsq;
+  float max_grad_norm;
+  float grad_scale;
+} HeroAdamWMulti;
+int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream);
+int hero_adamw_multi_chunk(void);
+
 #ifdef __cplusplus
 }
 #endif

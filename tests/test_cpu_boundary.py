@@ -41,7 +41,8 @@ def test_struct_layouts_match_header_sizes(built_lib):
     from hero_amd import _lib
     src = '#include <stdio.h>\n#include "hero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(HeroDropout),sizeof(HeroGemmEpilogue),sizeof(HeroLnFwd),sizeof(HeroLnBwd),' \
-          'sizeof(HeroAttn),sizeof(HeroAdamW));return 0;}\n'
+          'sizeof(HeroAttn),sizeof(HeroAdamW));printf("%zu %zu %zu\\n",sizeof(HeroTensorDesc),' \
+          'sizeof(HeroAdamWGroup),sizeof(HeroAdamWMulti));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "s.c"), "w") as f:
             f.write(src)
@@ -49,7 +50,8 @@ def test_struct_layouts_match_header_sizes(built_lib):
                                "-o", os.path.join(d, "s")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
     mine = [ctypes.sizeof(c) for c in (_lib.Dropout, _lib.GemmEpilogue, _lib.LnFwd, _lib.LnBwd,
-                                       _lib.Attn, _lib.AdamW)]
+                                       _lib.Attn, _lib.AdamW, _lib.TensorDesc, _lib.AdamWGroup,
+                                       _lib.AdamWMulti)]
     assert mine == sizes
 
 

@@ -1,0 +1,132 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing that replaces Horovod:
+gradient averaging, parameter broadcast, the flat gradient arena with bucketed async all-reduce
+(sink interface + stock-autograd hooks) and the cross-GPU negative gather whose backward has no
+collective (model/pretrain.py:427-447)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def spawn(fn, world=2):
+    ret = mp.Manager().dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _avg_and_broadcast(rank, world):
+    from hero_amd.utils import distributed as D
+    ts = [torch.full((3, 5), float(rank + 1)), torch.arange(7.0) * (rank + 1)]
+    D.all_reduce_and_rescale_tensors(ts, 2.0)          # average over ranks, then / 2
+    ok = torch.allclose(ts[0], torch.full((3, 5), 1.5 / 2)) and torch.allclose(ts[1], torch.arange(7.0) * 1.5 / 2)
+    ps = [torch.full((4,), float(rank)), torch.full((300000,), float(rank) + 5)]
+    D.broadcast_tensors(ps, 0, buffer_size=1024)
+    ok = ok and float(ps[0].sum()) == 0.0 and float(ps[1][0]) == 5.0
+    objs = D.all_gather_list({"r": rank})
+    ok = ok and [o["r"] for o in objs] == [0, 1] and D.any_broadcast("x%d" % rank, 1) == "x1"
+    return bool(ok)
+
+
+def test_average_broadcast_objects():
+    assert all(spawn(_avg_and_broadcast))
+
+
+def _arena(rank, world):
+    """Two-layer toy model: one parameter goes through stock autograd, one is accumulated by a fake
+    'kernel' through the sink interface (two uses per step, like the shared cross-modal encoder)."""
+    from hero_amd import functional as HF
+    from hero_amd.utils import distributed as D
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(6, 6))
+    w2 = torch.nn.Parameter(torch.randn(6, 6))
+    w3 = torch.nn.Parameter(torch.randn(5))           # never used -> stays zero, not 'touched'
+    arena = D.GradArena([w1, w2, w3], bucket_bytes=64, overlap=True)
+
+    class SinkMul(torch.autograd.Function):          # y = x @ w2, grad of w2 written via the sink
+        @staticmethod
+        def forward(ctx, x, w):
+            HF.SINK.use(w)
+            ctx.save_for_backward(x)
+            ctx.w = w
+            return x @ w.detach()
+
+        @staticmethod
+        def backward(ctx, dy):
+            (x,) = ctx.saved_tensors
+            HF.SINK.dst(ctx.w).add_(x.t() @ dy)
+            HF.SINK.done(ctx.w)
+            return dy @ ctx.w.detach().t(), None
+
+    def local_grads(r):
+        g = torch.Generator().manual_seed(10 + r)
+        x = torch.randn(4, 6, generator=g)
+        a, b = w1.detach().clone().requires_grad_(), w2.detach().clone().requires_grad_()
+        ((x @ a) @ b + (x @ b)).sum().backward()
+        return a.grad, b.grad
+
+    out = []
+    for micro in range(2):                            # gradient accumulation: sync only on the 2nd
+        arena.set_sync(micro == 1)
+        g = torch.Generator().manual_seed(10 + rank)
+        x = torch.randn(4, 6, generator=g)
+        h = x @ w1
+        y = SinkMul.apply(h, w2) + SinkMul.apply(x, w2)
+        y.sum().backward()
+    arena.finish()
+    arena.scale_(1.0 / world)
+    e1 = sum(local_grads(r)[0] for r in range(world)) * 2 / world
+    e2 = sum(local_grads(r)[1] for r in range(world)) * 2 / world
+    ok = torch.allclose(w1.grad, e1, atol=1e-5) and torch.allclose(w2.grad, e2, atol=1e-5)
+    ok = ok and w1.grad.data_ptr() == arena.flat.data_ptr() + arena.slices[w1][0] * 4
+    ok = ok and arena.touched == {w1, w2} and float(w3.grad.abs().sum()) == 0.0
+    arena.zero()
+    ok = ok and float(arena.flat.abs().sum()) == 0.0 and not arena.touched
+    HF.set_grad_sink(None)
+    return bool(ok)
+
+
+def test_grad_arena_bucketed_allreduce():
+    assert all(spawn(_arena))
+
+
+def _negatives(rank, world):
+    from hero_amd.utils import distributed as D
+    torch.manual_seed(rank)
+    nq, nv, ln = 2 + rank, 2 + rank, 3 + 2 * rank      # different sizes per rank
+    q = torch.randn(nq, 4, requires_grad=True)
+    c = torch.randn(nv, ln, 4, requires_grad=True)
+    m = torch.ones(nv, ln, dtype=torch.long)
+    Q, Cx, M = D.gather_negatives(q, c, m)
+    ok = Q.shape == (5, 4) and Cx.shape == (5, 5, 4) and M.shape == (5, 5)
+    off = 0 if rank == 0 else 2
+    ok = ok and torch.equal(Q[off:off + nq], q.detach()) and torch.equal(Cx[off:off + nv, :ln], c.detach())
+    ok = ok and float(M[:2, 3:].sum()) == 0 and float(M[2:].sum()) == 15       # rank 0's clips padded
+    w = torch.arange(5.0).view(5, 1)
+    ((Q * w).sum() + (Cx * w.view(5, 1, 1)).sum()).backward()
+    ok = ok and torch.allclose(q.grad, w[off:off + nq].expand(nq, 4))          # own slice only
+    ok = ok and torch.allclose(c.grad, w[off:off + nv].view(nv, 1, 1).expand(nv, ln, 4))
+    return bool(ok)
+
+
+def test_gather_negatives_slice_backward():
+    assert all(spawn(_negatives))

@@ -16,10 +16,10 @@ LAYOUT_K, LAYOUT_O = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_prof_enable", "hero_prof_read", "hero_layernorm_fwd",
+    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len",
-    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast",
+    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
 ]
 
@@ -120,6 +120,8 @@ def lib():
         L.hero_scatter_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hero_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.hero_transpose_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]
         L.hero_relu_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                     C.c_void_p]
         L.hero_gelu_bwd.argtypes = L.hero_relu_bwd.argtypes

@@ -299,10 +299,10 @@ template <typename T> static int max_len(int backward) {
 template <typename T, int LPK>
 static int launch_fwd(const HeroAttn& a, hipStream_t s) {
   const size_t lds = fwd_lds<T>(a.L);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET);
-    attr = true;
+  static size_t attr = 65536;   // raise the dynamic-LDS cap only when (and as far as) needed
+  if (lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
   }
   hipLaunchKernelGGL((attn_fwd_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
   return check_launch("hero_attention_fwd");
@@ -316,10 +316,10 @@ static int launch_bwd(const HeroAttn& a, hipStream_t s) {
   R &= ~3;
   if (R < 4) R = a.L < 4 ? a.L : 4;
   const size_t lds = fixed + (size_t)2 * R * Lp * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, LPK, KPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BUDGET + 8192));
-    attr = true;
+  static size_t attr = 65536;
+  if (lds > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, LPK, KPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
   }
   hipLaunchKernelGGL((attn_bwd_kernel<T, LPK, KPW>), dim3(a.S * a.H), dim3(256), lds, s, a, R);
   return check_launch("hero_attention_bwd");

@@ -1,18 +1,28 @@
 // MFMA GEMM with fused epilogues for gfx950 (MI355X).
 //
-//   C[M,N] = op(A) * op(B)   tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles
-//   bf16: v_mfma_f32_32x32x16_bf16, BK = 64 ; f32: v_mfma_f32_32x32x2_f32 (exact f32), BK = 32
+//   C[M,N] = op(A) * op(B)     bf16: v_mfma_f32_32x32x16_bf16, BK = 64
+//                              f32 : v_mfma_f32_32x32x2_f32 (exact f32), BK = 32
 //
-// LDS image of an operand tile is always [128 rows][128 bytes] with the eight 16-byte chunks of a
-// row XOR-swizzled by swz(row) = (row ^ row>>3) & 7, whatever the operand's layout in HBM:
-//   HERO_LAYOUT_K (reduction contiguous)  global 16 B -> LDS 16 B
-//   HERO_LAYOUT_O (outer dim contiguous)  4 reduction rows x 16 B are transposed in registers
-//                                         and written as 8 B (bf16) / 16 B (f32) pieces
-// so forward (x W^T), dgrad (dY W) and wgrad (dY^T X) run on the same main loop without any
-// transposed copies of weights or activations in HBM.
-// Staging is register-staged and split (issue loads for tile t+1, compute tile t, write LDS),
-// double-buffered, one barrier per K tile. The epilogue goes through LDS so that bias / residual /
-// aux / output traffic is 8-16 B per lane and coalesced along N.
+// Geometry is a template: WM x WN waves per workgroup, each wave owning TM x TN MFMA 32x32 tiles.
+//   Cfg<2,2,2,2>  128 x 128, 4 waves,  64 KiB LDS (2 workgroups / CU)
+//   Cfg<2,4,4,2>  256 x 256, 8 waves, 128 KiB LDS
+//
+// LDS image of an operand tile is always [rows][128 bytes] with the eight 16-byte chunks of a row
+// XOR-swizzled by swz(row) = (row ^ row>>3) & 7 (measured: SQ_LDS_BANK_CONFLICT = 0), whatever the
+// operand's layout in HBM:
+//   HERO_LAYOUT_K (reduction contiguous)  16 B global -> 16 B LDS
+//   HERO_LAYOUT_O (outer dim contiguous)  4 reduction rows x 16 B are transposed in registers and
+//                                         written as 8 B (bf16) / 16 B (f32) pieces
+// so forward (x W^T), dgrad (dY W) and wgrad (dY^T X) share one main loop and need no transposed
+// copies of weights or activations in HBM.
+// Staging is register-staged and split: loads for tile t+1 are issued before the MFMAs of tile t and
+// written to LDS after them; double-buffered LDS, one barrier per K tile.  All per-lane addressing
+// is computed once: a 32-bit element offset from a wave-uniform base pointer that the k-loop
+// advances with scalar arithmetic.  Rows outside the matrix are clamped to a valid row (they only
+// feed outputs that are never stored), so full tiles need no masking; only a partial last K tile
+// takes the masked path.  (A branch around a load makes hipcc wait vmcnt(0) per load.)
+// The epilogue goes through LDS (128 output rows at a time): bias is loaded once per thread, the
+// residual / aux / C loads of four rows are issued together, stores are 8-16 B per lane along N.
 #include "common.h"
 #include <vector>
 
@@ -21,151 +31,202 @@ namespace hero {
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int BM = 128, BN = 128, NT = 256;
-
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16_t> { static constexpr int BK = 64, EPC = 8; };
 template <> struct Tr<float>  { static constexpr int BK = 32, EPC = 4; };
 
-// ---------------------------------------------------------------------------------------------
-// global -> register -> LDS staging of one 128 x BK operand tile
-// ---------------------------------------------------------------------------------------------
-template <typename T, int LAY> struct Stage;
+template <int WM_, int WN_, int TM_, int TN_> struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int EPI_BYTES = 128 * BN * 4;                      // 128 output rows of fp32
+  static constexpr int LDS = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+};
 
-template <typename T> struct Stage<T, HERO_LAYOUT_K> {
-  uint4 v[4];
-  __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
+// ---------------------------------------------------------------------------------------------
+// global -> register -> LDS staging of one R x BK operand tile by NT threads
+// ---------------------------------------------------------------------------------------------
+template <typename T, int LAY, int R, int NT> struct Stage;
+
+template <typename T, int R, int NT> struct Stage<T, HERO_LAYOUT_K, R, NT> {
+  static constexpr int N = R * 8 / NT;
+  uint4 v[N];
+  int goff[N];    // element offset from the tile's uniform base (row0, k0)
+  int loff[N];    // LDS byte offset
+  int kcol[N];    // k offset (elements) of this chunk inside the tile, for the tail mask
+  __device__ __forceinline__ void init(int ld, int row0, int nrows) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < N; ++i) {
       const int q = threadIdx.x + NT * i;
       const int r = q >> 3, c = q & 7;
-      const int gr = row0 + r, gk = k0 + c * Tr<T>::EPC;
-      if (gr < nrows && gk < kend)
-        v[i] = *reinterpret_cast<const uint4*>(base + (size_t)gr * ld + gk);
-      else
-        v[i] = make_uint4(0, 0, 0, 0);
+      const int cr = min(row0 + r, nrows - 1) - row0;
+      goff[i] = cr * ld + c * Tr<T>::EPC;
+      loff[i] = r * 128 + ((c ^ swz(r)) << 4);
+      kcol[i] = c * Tr<T>::EPC;
+    }
+  }
+  static __device__ __forceinline__ const T* base(const T* p, int ld, int row0, int k) { return p + (size_t)row0 * ld + k; }
+  static __device__ __forceinline__ const T* advance(const T* b, int) { return b + Tr<T>::BK; }
+  __device__ __forceinline__ void load(const T* __restrict__ b) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = *reinterpret_cast<const uint4*>(b + goff[i]);
+  }
+  __device__ __forceinline__ void load_tail(const T* __restrict__ b, int krem) {   // krem = valid k in this tile
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int back = kcol[i] < krem ? 0 : kcol[i] - (krem - Tr<T>::EPC);           // stay inside the row
+      v[i] = *reinterpret_cast<const uint4*>(b + goff[i] - back);
     }
   }
   __device__ __forceinline__ void store(char* lds) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = threadIdx.x + NT * i;
-      const int r = q >> 3, c = q & 7;
-      *reinterpret_cast<uint4*>(lds + r * 128 + ((c ^ swz(r)) << 4)) = v[i];
+    for (int i = 0; i < N; ++i) *reinterpret_cast<uint4*>(lds + loff[i]) = v[i];
+  }
+  __device__ __forceinline__ void store_tail(char* lds, int krem) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const bool ok = kcol[i] < krem;
+      uint4 t = v[i];
+      t.x = ok ? t.x : 0u; t.y = ok ? t.y : 0u; t.z = ok ? t.z : 0u; t.w = ok ? t.w : 0u;
+      *reinterpret_cast<uint4*>(lds + loff[i]) = t;
     }
   }
 };
 
-template <> struct Stage<bf16_t, HERO_LAYOUT_O> {
-  uint4 v[4];  // 4 reduction rows x 8 outer elements
-  __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
-    const int og = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int go = row0 + og * 8;
+// outer-contiguous operands: thread slot = (out group of EPC elements) x (reduction group of 4); 2R slots.
+// The 4 x EPC block is transposed in registers and written as EPC pieces of 4 reduction elements.
+template <typename T, int R, int NT> struct Stage<T, HERO_LAYOUT_O, R, NT> {
+  static constexpr int EPC = Tr<T>::EPC;
+  static constexpr int N = (2 * R + NT - 1) / NT, OG = R / EPC;   // threads beyond 2R slots idle
+  uint4 v[N][4];
+  int goff[N];      // element offset of (reduction row rg*4, outer og*EPC) from the uniform base
+  int loff[N];      // LDS byte offset of outer row og*EPC, reduction group rg (before the per-row swizzle)
+  int krow[N];      // first reduction row of the slot inside the tile
+  int ld_;
+  __device__ __forceinline__ void init(int ld, int row0, int nrows) {
+    ld_ = ld;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gk = k0 + rg * 4 + j;
-      if (gk < kend && go < nrows)
-        v[j] = *reinterpret_cast<const uint4*>(base + (size_t)gk * ld + go);
-      else
-        v[j] = make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < N; ++s) {
+      const int q = threadIdx.x + NT * s;
+      const int og = q % OG, rg = q / OG;
+      const int co = min(row0 + og * EPC, nrows - EPC) - row0;
+      goff[s] = rg * 4 * ld + co;
+      loff[s] = og * EPC * 128 + rg * (sizeof(T) * 4);      // + swizzle of the chunk index per row in store()
+      krow[s] = (2 * R < NT * N && q >= 2 * R) ? 1 << 20 : rg * 4;   // idle slot: never valid
     }
   }
-  __device__ __forceinline__ void store(char* lds) const {
-    const int og = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const uint32_t w0[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
-    const uint32_t w1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
-    const uint32_t w2[4] = {v[2].x, v[2].y, v[2].z, v[2].w};
-    const uint32_t w3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+  static __device__ __forceinline__ const T* base(const T* p, int ld, int row0, int k) { return p + (size_t)k * ld + row0; }
+  static __device__ __forceinline__ const T* advance(const T* b, int ld) { return b + (size_t)Tr<T>::BK * ld; }
+  __device__ __forceinline__ void load(const T* __restrict__ b) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int w = e >> 1;
-      uint2 o;
-      if (e & 1) {
-        o.x = (w0[w] >> 16) | (w1[w] & 0xffff0000u);
-        o.y = (w2[w] >> 16) | (w3[w] & 0xffff0000u);
-      } else {
-        o.x = (w0[w] & 0xffffu) | (w1[w] << 16);
-        o.y = (w2[w] & 0xffffu) | (w3[w] << 16);
+    for (int s = 0; s < N; ++s) {
+      if (2 * R < NT * N && krow[s] >= (1 << 20)) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[s][j] = *reinterpret_cast<const uint4*>(b + goff[s] + j * ld_);
+    }
+  }
+  __device__ __forceinline__ void load_tail(const T* __restrict__ b, int krem) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      if (2 * R < NT * N && krow[s] >= (1 << 20)) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kr = krow[s] + j;
+        const int back = kr < krem ? 0 : kr - (krem - 1);                           // clamp to the last valid row
+        v[s][j] = *reinterpret_cast<const uint4*>(b + goff[s] + (j - back) * ld_);
       }
-      const int r = og * 8 + e;
-      *reinterpret_cast<uint2*>(lds + r * 128 + (((rg >> 1) ^ swz(r)) << 4) + ((rg & 1) << 3)) = o;
     }
   }
-};
-
-template <> struct Stage<float, HERO_LAYOUT_O> {
-  float4 v[4];  // 4 reduction rows x 4 outer elements
-  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend) {
-    const int og = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int go = row0 + og * 4;
+  __device__ __forceinline__ void store_impl(char* lds, int krem) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gk = k0 + rg * 4 + j;
-      if (gk < kend && go < nrows)
-        v[j] = *reinterpret_cast<const float4*>(base + (size_t)gk * ld + go);
-      else
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  __device__ __forceinline__ void store(char* lds) const {
-    const int og = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const float c0[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
-    const float c1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
-    const float c2[4] = {v[2].x, v[2].y, v[2].z, v[2].w};
-    const float c3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+    for (int s = 0; s < N; ++s) {
+      if (2 * R < NT * N && krow[s] >= (1 << 20)) continue;
+      uint32_t w[4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = og * 4 + e;
-      *reinterpret_cast<float4*>(lds + r * 128 + ((rg ^ swz(r)) << 4)) = make_float4(c0[e], c1[e], c2[e], c3[e]);
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t m = (krow[s] + j < krem) ? 0xffffffffu : 0u;
+        w[j][0] = v[s][j].x & m; w[j][1] = v[s][j].y & m; w[j][2] = v[s][j].z & m; w[j][3] = v[s][j].w & m;
+      }
+      const int r0 = loff[s] >> 7;                 // og * EPC
+      const int inrow = loff[s] & 127;             // byte position of the reduction group in a row
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int r = r0 + e;
+        char* dst = lds + r * 128 + ((((inrow >> 4) ^ swz(r)) << 4) | (inrow & 15));
+        if (sizeof(T) == 2) {
+          const int c = e >> 1;
+          uint2 o;
+          if (e & 1) {
+            o.x = (w[0][c] >> 16) | (w[1][c] & 0xffff0000u);
+            o.y = (w[2][c] >> 16) | (w[3][c] & 0xffff0000u);
+          } else {
+            o.x = (w[0][c] & 0xffffu) | (w[1][c] << 16);
+            o.y = (w[2][c] & 0xffffu) | (w[3][c] << 16);
+          }
+          *reinterpret_cast<uint2*>(dst) = o;
+        } else {
+          *reinterpret_cast<uint4*>(dst) = make_uint4(w[0][e], w[1][e], w[2][e], w[3][e]);
+        }
+      }
     }
   }
+  __device__ __forceinline__ void store(char* lds) const { store_impl(lds, 1 << 19); }
+  __device__ __forceinline__ void store_tail(char* lds, int krem) const { store_impl(lds, krem); }
 };
 
 // ---------------------------------------------------------------------------------------------
-// one K tile of MFMA work for a wave: acc[2][2] += A(64 x BK) * B(64 x BK)^T
+// one K tile of MFMA work for a wave: acc[TM][TN] += A(TM*32 x BK) * B(TN*32 x BK)^T
 // ---------------------------------------------------------------------------------------------
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static __device__ __forceinline__ void tile(const char* la, const char* lb, int wm, int wn, int lane, f32x16_t (&acc)[2][2]) {
+template <typename T, int TM, int TN> struct Mma;
+template <int TM, int TN> struct Mma<bf16_t, TM, TN> {
+  static __device__ __forceinline__ void tile(const char* la, const char* lb, int arow0, int brow0, int lane, f32x16_t (&acc)[TM][TN]) {
     const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8_t a[2], b[2];
+      const int kc = ks * 2 + kg;
+      bf16x8_t a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + r;
-        a[i] = *reinterpret_cast<const bf16x8_t*>(la + ra * 128 + (((ks * 2 + kg) ^ swz(ra)) << 4));
-        const int rb = wn * 64 + i * 32 + r;
-        b[i] = *reinterpret_cast<const bf16x8_t*>(lb + rb * 128 + (((ks * 2 + kg) ^ swz(rb)) << 4));
+      for (int i = 0; i < TM; ++i) {
+        const int ra = arow0 + i * 32 + r;
+        a[i] = *reinterpret_cast<const bf16x8_t*>(la + ra * 128 + ((kc ^ swz(ra)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TN; ++j) {
+        const int rb = brow0 + j * 32 + r;
+        b[j] = *reinterpret_cast<const bf16x8_t*>(lb + rb * 128 + ((kc ^ swz(rb)) << 4));
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
 };
-template <> struct Mma<float> {
-  static __device__ __forceinline__ void tile(const char* la, const char* lb, int wm, int wn, int lane, f32x16_t (&acc)[2][2]) {
+template <int TM, int TN> struct Mma<float, TM, TN> {
+  static __device__ __forceinline__ void tile(const char* la, const char* lb, int arow0, int brow0, int lane, f32x16_t (&acc)[TM][TN]) {
     const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const int k = ks * 2 + kg;  // 0..31 within the tile
-      float a[2], b[2];
+      float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + r;
+      for (int i = 0; i < TM; ++i) {
+        const int ra = arow0 + i * 32 + r;
         a[i] = *reinterpret_cast<const float*>(la + ra * 128 + (((k >> 2) ^ swz(ra)) << 4) + ((k & 3) << 2));
-        const int rb = wn * 64 + i * 32 + r;
-        b[i] = *reinterpret_cast<const float*>(lb + rb * 128 + (((k >> 2) ^ swz(rb)) << 4) + ((k & 3) << 2));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TN; ++j) {
+        const int rb = brow0 + j * 32 + r;
+        b[j] = *reinterpret_cast<const float*>(lb + rb * 128 + (((k >> 2) ^ swz(rb)) << 4) + ((k & 3) << 2));
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
@@ -180,12 +241,120 @@ struct GemmArgs {
   HeroGemmEpilogue epi;
 };
 
-template <typename T, int ALAY, int BLAY>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 64 KiB: 2 x (A 16K | B 16K); reused as the C tile
-  constexpr int BK = Tr<T>::BK;
+// ---------------------------------------------------------------------------------------------
+// epilogue shared by both staging flavours
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename CF>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)[CF::TM][CF::TN], char* smem, int m0, int n0,
+                                              int arow0, int brow0, int lane) {
+  constexpr int BM = CF::BM, BN = CF::BN, NT = CF::NT, TM = CF::TM, TN = CF::TN;
+  const HeroGemmEpilogue& e = g.epi;
+  // ---- split-K: fp32 atomics straight from the accumulator layout
+  if (e.split_k > 1) {
+    float* C = static_cast<float*>(g.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + brow0 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gm = m0 + arow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (gm < g.M && gn < g.N) atomicAdd(C + (size_t)gm * g.ldc + gn, acc[i][j][r]);
+        }
+      }
+    return;
+  }
 
-  // ---- workgroup -> (split, tile): XCD-contiguous chunks, then grouped along M for L2 reuse
+  // ---- accumulators -> LDS (128 rows x BN fp32 per pass) -> vectorised epilogue
+  float* lc = reinterpret_cast<float*>(smem);
+  DropCtx drop(e.dropout);
+  const T* R = static_cast<const T*>(e.residual);
+  T* X = static_cast<T*>(e.aux);
+  constexpr int PASSES = BM / 128;
+  constexpr int C4 = BN / 4;                        // float4 per row
+  constexpr int ITERS = 128 * C4 / NT;
+#pragma unroll 1
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if (pass) __syncthreads();
+    if (arow0 / 128 == pass) {
+      const int rbase = arow0 - pass * 128;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = brow0 + j * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            lc[row * BN + col] = acc[i][j][r];
+          }
+        }
+    }
+    __syncthreads();
+    // this thread's column group is the same in every iteration (NT is a multiple of C4)
+    const int c4 = (threadIdx.x % C4) * 4;
+    const int gn = n0 + c4;
+    const bool col_ok = gn < g.N;
+    const int gnc = min(gn, g.N - 4);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.bias) bias4 = *reinterpret_cast<const float4*>(e.bias + gnc);
+    const bool ld_aux = e.act == HERO_ACT_GELU_BWD || e.act == HERO_ACT_RELU_BWD;
+    const bool ld_c = e.out_f32 && e.beta != 0.f;
+    constexpr int RSTEP = NT / C4;                 // rows covered per iteration
+    constexpr int UN = 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += UN) {
+      size_t off[UN];
+      bool ok[UN];
+      float4 rr[UN], uu[UN], cc[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {               // all global loads of the group first (batched)
+        const int row = threadIdx.x / C4 + (it0 + u) * RSTEP;
+        const int gm = m0 + pass * 128 + row;
+        ok[u] = col_ok && gm < g.M;
+        off[u] = (size_t)min(gm, g.M - 1) * g.ldc + gnc;
+        if (R) rr[u] = V4<T>::ld(R + off[u]);
+        if (ld_aux) uu[u] = V4<T>::ld(X + off[u]);
+        if (ld_c) cc[u] = *reinterpret_cast<const float4*>(static_cast<const float*>(g.C) + off[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int row = threadIdx.x / C4 + (it0 + u) * RSTEP;
+        float4 v = *reinterpret_cast<const float4*>(lc + row * BN + c4);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (e.act == HERO_ACT_GELU) {
+          if (ok[u]) V4<T>::st(X + off[u], v);
+          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        } else if (e.act == HERO_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          if (X && ok[u]) V4<T>::st(X + off[u], v);
+        } else if (e.act == HERO_ACT_GELU_BWD) {
+          v.x *= gelu_erf_grad(uu[u].x); v.y *= gelu_erf_grad(uu[u].y); v.z *= gelu_erf_grad(uu[u].z); v.w *= gelu_erf_grad(uu[u].w);
+        } else if (e.act == HERO_ACT_RELU_BWD) {
+          v.x = uu[u].x > 0.f ? v.x : 0.f; v.y = uu[u].y > 0.f ? v.y : 0.f; v.z = uu[u].z > 0.f ? v.z : 0.f; v.w = uu[u].w > 0.f ? v.w : 0.f;
+        }
+        if (drop.on()) {
+          const int gm = m0 + pass * 128 + row;
+          const float4 mk = drop.mask4(((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2);
+          v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+        }
+        if (R) { v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w; }
+        if (e.out_f32) {
+          if (ld_c) { v.x += e.beta * cc[u].x; v.y += e.beta * cc[u].y; v.z += e.beta * cc[u].z; v.w += e.beta * cc[u].w; }
+          if (ok[u]) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + off[u]) = v;
+        } else {
+          if (ok[u]) V4<T>::st(static_cast<T*>(g.C) + off[u], v);
+        }
+      }
+    }
+  }
+}
+
+// workgroup -> (split, tile): XCD-contiguous chunks, then grouped along M for L2 reuse
+struct TileCoord { int m0, n0, kbeg, kend; };
+template <typename CF>
+__device__ __forceinline__ TileCoord tile_coord(const GemmArgs& g) {
   const int nwg = gridDim.x;
   int wg;
   {
@@ -201,131 +370,153 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
   const int first_m = group * GROUP;
   const int gsz = min(g.tiles_m - first_m, GROUP);
   const int in_group = tile - group * per_group;
-  const int pid_m = first_m + in_group % gsz;
-  const int pid_n = in_group / gsz;
-  const int m0 = pid_m * BM, n0 = pid_n * BN;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
+  TileCoord t;
+  t.m0 = (first_m + in_group % gsz) * CF::BM;
+  t.n0 = (in_group / gsz) * CF::BN;
+  t.kbeg = split * g.k_per_split;
+  t.kend = min(g.K, t.kbeg + g.k_per_split);
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct-to-LDS staging (global_load_lds, 16 B per lane) for K-contiguous operands, K % BK == 0.
+// One wave instruction fills 8 consecutive tile rows (8 x 128 B, lane-linear in LDS); the chunk
+// swizzle is applied on the SOURCE address (lane (row, c') fetches chunk c' ^ swz(row)).
+// No staging VGPRs, no ds_write: the VGPR->LDS write path is what bounds the register-staged loop.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int R, int NT>
+struct GldsStage {
+  static constexpr int PER_WAVE = R / 8 / (NT / 64);     // instructions per wave per tile
+  int goff[PER_WAVE];                                      // element offset from the uniform base
+  int lrow0;                                               // first tile row of this wave's first instruction
+  __device__ __forceinline__ void init(int ld, int row0, int nrows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lrow0 = wave * (R / (NT / 64));
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int r = lrow0 + i * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ swz(r);
+      goff[i] = (min(row0 + r, nrows - 1) - row0) * ld + c * Tr<T>::EPC;
+    }
+  }
+  __device__ __forceinline__ void issue(const T* __restrict__ b, char* lds) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds(b + goff[i], (__attribute__((address_space(3))) void*)(lds + (lrow0 + i * 8) * 128), 16, 0, 0);
+  }
+};
+
+template <typename T, typename CF>
+__global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_glds_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Tr<T>::BK, BM = CF::BM, BN = CF::BN, NT = CF::NT, TM = CF::TM, TN = CF::TN;
+  const TileCoord tc = tile_coord<CF>(g);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / CF::WN, wn = wave % CF::WN;
+  const int arow0 = wm * TM * 32, brow0 = wn * TN * 32;
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  GldsStage<T, BM, NT> sa;
+  GldsStage<T, BN, NT> sb;
+  sa.init(g.lda, m0, g.M);
+  sb.init(g.ldb, n0, g.N);
+  const T* pa = static_cast<const T*>(g.A) + (size_t)m0 * g.lda + tc.kbeg;
+  const T* pb = static_cast<const T*>(g.B) + (size_t)n0 * g.ldb + tc.kbeg;
+  const int nk = (tc.kend - tc.kbeg) / BK;
+  if (nk > 0) {
+    sa.issue(pa, smem);
+    sb.issue(pb, smem + CF::A_BYTES);
+  }
+  // An LDS-DMA is ordered for other waves' ds_reads only by the issuing wave's vmcnt + a barrier.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // tile 0 has landed
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * CF::STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * CF::STAGE;
+    if (kt + 1 < nk) {
+      pa += BK;
+      pb += BK;
+      sa.issue(pa, nxt);
+      sb.issue(pb, nxt + CF::A_BYTES);
+    }
+    Mma<T, TM, TN>::tile(cur, cur + CF::A_BYTES, arow0, brow0, lane, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // next tile landed, everyone done with cur
+  }
+  gemm_epilogue<T, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
+}
+
+template <typename T, int ALAY, int BLAY, typename CF>
+__global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Tr<T>::BK, BM = CF::BM, BN = CF::BN, NT = CF::NT, TM = CF::TM, TN = CF::TN;
+
+  const TileCoord tc = tile_coord<CF>(g);
+  const int m0 = tc.m0, n0 = tc.n0, kbeg = tc.kbeg, kend = tc.kend;
 
   const T* A = static_cast<const T*>(g.A);
   const T* B = static_cast<const T*>(g.B);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / CF::WN, wn = wave % CF::WN;
+  const int arow0 = wm * TM * 32, brow0 = wn * TN * 32;
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  Stage<T, ALAY> sa;
-  Stage<T, BLAY> sb;
+  typedef Stage<T, ALAY, BM, NT> SA;
+  typedef Stage<T, BLAY, BN, NT> SB;
+  SA sa;
+  SB sb;
+  sa.init(g.lda, m0, g.M);
+  sb.init(g.ldb, n0, g.N);
+  const T* pa = SA::base(A, g.lda, m0, kbeg);   // wave-uniform, advanced per K tile
+  const T* pb = SB::base(B, g.ldb, n0, kbeg);
   const int nk = (kend - kbeg + BK - 1) / BK;
+  const int ktail = (kend - kbeg) - (nk - 1) * BK;                    // valid k in the last tile (1..BK)
+  const bool has_tail = ktail != BK;
   if (nk > 0) {
-    sa.load(A, g.lda, m0, g.M, kbeg, kend);
-    sb.load(B, g.ldb, n0, g.N, kbeg, kend);
-    sa.store(smem);
-    sb.store(smem + 16384);
+    if (nk == 1 && has_tail) {
+      sa.load_tail(pa, ktail); sb.load_tail(pb, ktail);
+      sa.store_tail(smem, ktail); sb.store_tail(smem + CF::A_BYTES, ktail);
+    } else {
+      sa.load(pa); sb.load(pb);
+      sa.store(smem); sb.store(smem + CF::A_BYTES);
+    }
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * 32768;
-    char* nxt = smem + ((kt + 1) & 1) * 32768;
+    char* cur = smem + (kt & 1) * CF::STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * CF::STAGE;
     const bool more = kt + 1 < nk;
+    const bool tail_next = has_tail && kt + 2 == nk;
     if (more) {
-      sa.load(A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend);
-      sb.load(B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend);
+      pa = SA::advance(pa, g.lda);
+      pb = SB::advance(pb, g.ldb);
+      if (tail_next) { sa.load_tail(pa, ktail); sb.load_tail(pb, ktail); }
+      else { sa.load(pa); sb.load(pb); }
     }
-    Mma<T>::tile(cur, cur + 16384, wm, wn, lane, acc);
+    Mma<T, TM, TN>::tile(cur, cur + CF::A_BYTES, arow0, brow0, lane, acc);
     if (more) {
-      sa.store(nxt);
-      sb.store(nxt + 16384);
+      if (tail_next) { sa.store_tail(nxt, ktail); sb.store_tail(nxt + CF::A_BYTES, ktail); }
+      else { sa.store(nxt); sb.store(nxt + CF::A_BYTES); }
     }
     __syncthreads();
   }
 
-  const HeroGemmEpilogue& e = g.epi;
-  // ---- split-K: fp32 atomics straight from the accumulator layout
-  if (e.split_k > 1) {
-    float* C = static_cast<float*>(g.C);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (gm < g.M && gn < g.N) atomicAdd(C + (size_t)gm * g.ldc + gn, acc[i][j][r]);
-        }
-      }
-    return;
-  }
-
-  // ---- accumulators -> LDS C tile [128][128] fp32
-  float* lc = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        lc[row * BN + col] = acc[i][j][r];
-      }
-    }
-  __syncthreads();
-
-  DropCtx drop(e.dropout);
-  const T* R = static_cast<const T*>(e.residual);
-  T* X = static_cast<T*>(e.aux);
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int q = threadIdx.x + NT * it;
-    const int row = q >> 5, c4 = (q & 31) * 4;
-    const int gm = m0 + row, gn = n0 + c4;
-    if (gm >= g.M || gn >= g.N) continue;
-    float4 v = *reinterpret_cast<const float4*>(lc + row * BN + c4);
-    const size_t off = (size_t)gm * g.ldc + gn;
-    if (e.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(e.bias + gn);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    if (e.act == HERO_ACT_GELU) {
-      V4<T>::st(X + off, v);
-      v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-    } else if (e.act == HERO_ACT_RELU) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      if (X) V4<T>::st(X + off, v);
-    } else if (e.act == HERO_ACT_GELU_BWD) {
-      const float4 u = V4<T>::ld(X + off);
-      v.x *= gelu_erf_grad(u.x); v.y *= gelu_erf_grad(u.y); v.z *= gelu_erf_grad(u.z); v.w *= gelu_erf_grad(u.w);
-    } else if (e.act == HERO_ACT_RELU_BWD) {
-      const float4 u = V4<T>::ld(X + off);
-      v.x = u.x > 0.f ? v.x : 0.f; v.y = u.y > 0.f ? v.y : 0.f; v.z = u.z > 0.f ? v.z : 0.f; v.w = u.w > 0.f ? v.w : 0.f;
-    }
-    if (drop.on()) {
-      const float4 mk = drop.mask4(((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2);
-      v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
-    }
-    if (R) {
-      const float4 rr = V4<T>::ld(R + off);
-      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-    }
-    if (e.out_f32) {
-      float* C = static_cast<float*>(g.C) + off;
-      if (e.beta != 0.f) {
-        const float4 o = *reinterpret_cast<const float4*>(C);
-        v.x += e.beta * o.x; v.y += e.beta * o.y; v.z += e.beta * o.z; v.w += e.beta * o.w;
-      }
-      *reinterpret_cast<float4*>(C) = v;
-    } else {
-      V4<T>::st(static_cast<T*>(g.C) + off, v);
-    }
-  }
+  gemm_epilogue<T, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
 
 // out <- beta * out over an [M, N] fp32 matrix (pre-pass of the split-K atomics path)
@@ -351,14 +542,20 @@ struct ProfSlot {
 };
 static ProfSlot g_prof[8];
 static bool g_prof_on = false;
+static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2); -1 = heuristic
 
-template <typename T, int AL, int BL>
-static int launch(const GemmArgs& g, hipStream_t s) {
+typedef Cfg<2, 2, 2, 2> Cfg128;
+typedef Cfg<2, 4, 4, 2> Cfg256;
+
+template <typename T, int AL, int BL, typename CF>
+static int launch(GemmArgs g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AL, BL>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AL, BL, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
     attr_set = true;
   }
+  g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
+  g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
   const int split = g.epi.split_k > 1 ? g.epi.split_k : 1;
   const int grid = g.tiles_m * g.tiles_n * split;
   ProfSlot* ps = nullptr;
@@ -371,7 +568,7 @@ static int launch(const GemmArgs& g, hipStream_t s) {
       ps = nullptr;
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<T, AL, BL>), dim3(grid), dim3(NT), 65536, s, g);
+  hipLaunchKernelGGL((gemm_kernel<T, AL, BL, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, g);
   if (ps) {
     (void)hipEventRecord(e1, s);
     ps->ev.push_back(e0);
@@ -381,12 +578,65 @@ static int launch(const GemmArgs& g, hipStream_t s) {
   return check_launch("hero_gemm");
 }
 
+// Geometry choice (measured on MI355X, tools/gemm_bench.py): the 128x128 tile with two resident
+// workgroups per CU is the best or within a few % of the best on every shape of the HERO step; the
+// 256x256 tile wins ~5 % on the largest K-contiguous problems only.
+static int pick_cfg(int M, int N, int split, bool k_contig) {
+  if (g_force_cfg >= 0) return g_force_cfg;
+  if (k_contig && split == 1 && (long long)((M + 255) / 256) * ((N + 255) / 256) >= 256) return 2;
+  return 0;
+}
+
+static int g_use_glds = 1;   // tuning hook
+
+template <typename T, typename CF>
+static int launch_glds(GemmArgs g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
+    attr_set = true;
+  }
+  g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
+  g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
+  const int split = g.epi.split_k > 1 ? g.epi.split_k : 1;
+  const int grid = g.tiles_m * g.tiles_n * split;
+  ProfSlot* ps = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof_on) {
+    ps = &g_prof[(sizeof(T) == 2 ? 4 : 0)];
+    if (ps->flops.size() < 16384 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      (void)hipEventRecord(e0, s);
+    } else {
+      ps = nullptr;
+    }
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, g);
+  if (ps) {
+    (void)hipEventRecord(e1, s);
+    ps->ev.push_back(e0);
+    ps->ev.push_back(e1);
+    ps->flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
+  }
+  return check_launch("hero_gemm(glds)");
+}
+
+template <typename T, int AL, int BL>
+static int launch_cfg(const GemmArgs& g, int cfg, hipStream_t s) {
+  if (AL == HERO_LAYOUT_K && BL == HERO_LAYOUT_K && g_use_glds && g.K > 0 && g.K % Tr<T>::BK == 0 &&
+      g.k_per_split % Tr<T>::BK == 0) {
+    if (cfg == 2) return launch_glds<T, Cfg256>(g, s);
+    return launch_glds<T, Cfg128>(g, s);
+  }
+  if (cfg == 2) return launch<T, AL, BL, Cfg256>(g, s);
+  return launch<T, AL, BL, Cfg128>(g, s);
+}
+
 template <typename T>
-static int dispatch(const GemmArgs& g, int al, int bl, hipStream_t s) {
-  if (al == HERO_LAYOUT_K && bl == HERO_LAYOUT_K) return launch<T, HERO_LAYOUT_K, HERO_LAYOUT_K>(g, s);
-  if (al == HERO_LAYOUT_K && bl == HERO_LAYOUT_O) return launch<T, HERO_LAYOUT_K, HERO_LAYOUT_O>(g, s);
-  if (al == HERO_LAYOUT_O && bl == HERO_LAYOUT_O) return launch<T, HERO_LAYOUT_O, HERO_LAYOUT_O>(g, s);
-  if (al == HERO_LAYOUT_O && bl == HERO_LAYOUT_K) return launch<T, HERO_LAYOUT_O, HERO_LAYOUT_K>(g, s);
+static int dispatch(const GemmArgs& g, int al, int bl, int cfg, hipStream_t s) {
+  if (al == HERO_LAYOUT_K && bl == HERO_LAYOUT_K) return launch_cfg<T, HERO_LAYOUT_K, HERO_LAYOUT_K>(g, cfg, s);
+  if (al == HERO_LAYOUT_K && bl == HERO_LAYOUT_O) return launch_cfg<T, HERO_LAYOUT_K, HERO_LAYOUT_O>(g, cfg, s);
+  if (al == HERO_LAYOUT_O && bl == HERO_LAYOUT_O) return launch_cfg<T, HERO_LAYOUT_O, HERO_LAYOUT_O>(g, cfg, s);
+  if (al == HERO_LAYOUT_O && bl == HERO_LAYOUT_K) return launch_cfg<T, HERO_LAYOUT_O, HERO_LAYOUT_K>(g, cfg, s);
   set_error("hero_gemm: bad layout (%d, %d)", al, bl);
   return HERO_ERR_ARG;
 }
@@ -415,10 +665,10 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   GemmArgs g;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.tiles_m = (M + BM - 1) / BM;
-  g.tiles_n = (N + BN - 1) / BN;
+  g.tiles_m = g.tiles_n = 0;
   g.epi = *epi;
   const int bk = dtype == HERO_BF16 ? 64 : 32;
+  const bool k_contig = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (epi->split_k > 1) {
     HERO_REQUIRE(epi->out_f32 && epi->act == HERO_ACT_NONE && !epi->bias && !epi->residual && epi->dropout.threshold16 == 0,
@@ -436,13 +686,22 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
         }
         g.k_per_split = per * bk;
         g.epi.split_k = split;
-        return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, s) : dispatch<float>(g, a_layout, b_layout, s);
+        const int cfg = pick_cfg(M, N, split, k_contig);
+        return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, cfg, s) : dispatch<float>(g, a_layout, b_layout, cfg, s);
       }
     }
   }
   g.k_per_split = K > 0 ? ((K + bk - 1) / bk) * bk : bk;
   g.epi.split_k = 1;
-  return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, s) : dispatch<float>(g, a_layout, b_layout, s);
+  const int cfg = pick_cfg(M, N, 1, k_contig);
+  return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, cfg, s) : dispatch<float>(g, a_layout, b_layout, cfg, s);
+}
+
+// Tuning hook: force a tile geometry (0: 128x128, 1: 128x256, 2: 256x256, -1: heuristic).
+extern "C" int hero_gemm_force_config(int cfg) {
+  g_force_cfg = cfg >= 0 ? (cfg & 3) : -1;
+  g_use_glds = cfg >= 0 ? !(cfg & 4) : 1;      // bit 2 set: register staging even for K,K operands
+  return HERO_OK;
 }
 
 // Per-launch timing of the GEMM kernels with HIP events on the launch stream (used by bench.py

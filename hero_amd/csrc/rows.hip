@@ -74,6 +74,25 @@ __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, size_t
     V4<TD>::st(d + q * 4, V4<TS>::ld(s + q * 4));
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1<TD>(d + n4 * 4 + threadIdx.x, ld1<TS>(s + n4 * 4 + threadIdx.x));
 }
+// dst[c * ldd + r] = (TD) src[r * C + c]   (32x32 tiles through LDS, both sides coalesced)
+template <typename TD>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, TD* __restrict__ dst, int R, int C, int ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < C && r < R) st1<TD>(dst + (size_t)c * ldd + r, tile[tx][ty + 8 * k]);
+  }
+}
+
 template <typename T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t n) {
   const size_t n4 = n >> 2;
@@ -293,6 +312,17 @@ extern "C" int hero_cast(const void* src, void* dst, size_t n, int sd, int dd, h
   else if (sd == HERO_BF16 && dd == HERO_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else { set_error("hero_cast: bad dtypes %d -> %d", sd, dd); return HERO_ERR_ARG; }
   return check_launch("hero_cast");
+}
+
+extern "C" int hero_transpose_cast(const float* src, void* dst, int rows, int cols, int ldd, int dst_dtype, hero_stream_t stream) {
+  HERO_REQUIRE(src && dst, "hero_transpose_cast: null pointer");
+  if (rows <= 0 || cols <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  if (dst_dtype == HERO_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, ldd);
+  else if (dst_dtype == HERO_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, rows, cols, ldd);
+  else { set_error("hero_transpose_cast: bad dtype %d", dst_dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_transpose_cast");
 }
 
 extern "C" int hero_relu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, hero_stream_t stream) {

@@ -111,14 +111,38 @@ def packed(params, dtype):
     if hit is not None and hit[0] == sig:
         return hit[1]
     rows = sum(p.shape[0] for p in params)
-    out = hit[1] if hit is not None else torch.empty((rows,) + tuple(params[0].shape[1:]),
-                                                     dtype=dtype, device=params[0].device)
+    shape = (rows,) + tuple(params[0].shape[1:])
+    reuse = hit is not None and tuple(hit[1].shape) == shape and hit[1].device == params[0].device
+    out = hit[1] if reuse else torch.empty(shape, dtype=dtype, device=params[0].device)
     off = 0
     for p in params:
         n = p.numel()
         dst = out[off:off + p.shape[0]]
         L.check(L.lib().hero_cast(L.ptr(p.detach().contiguous()), dst.data_ptr(), n, L.F32,
                                   L.dt(out), L.stream()))
+        off += p.shape[0]
+    _WCACHE[key] = (sig, out)
+    return out
+
+
+def packed_t(params, dtype):
+    """Transposed compute copy: [K_in, sum_i N_i] = concat_i(p_i^T) (cached like `packed`), used as
+    the K-contiguous B operand of dgrad: dX = dY @ W  ==  dY @ (W^T)^T."""
+    params = tuple(params)
+    key = (tuple(id(p) for p in params), dtype, "T")
+    sig = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), _WEPOCH[0])
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    kin = params[0].shape[1]
+    cols = sum(p.shape[0] for p in params)
+    reuse = hit is not None and tuple(hit[1].shape) == (kin, cols) and hit[1].device == params[0].device
+    out = hit[1] if reuse else torch.empty((kin, cols), dtype=dtype, device=params[0].device)
+    off = 0
+    for p in params:
+        L.check(L.lib().hero_transpose_cast(L.ptr(p.detach().contiguous()),
+                                            out.data_ptr() + off * out.element_size(), p.shape[0], kin,
+                                            cols, L.dt(out), L.stream()))
         off += p.shape[0]
     _WCACHE[key] = (sig, out)
     return out
@@ -194,11 +218,22 @@ def k_linear(x2, Wc, bias=None, act=L.ACT_NONE, aux=None, residual=None, drop=No
 
 
 def k_dgrad(dy2, Wc, act=L.ACT_NONE, aux=None, residual=None):
-    """dx[M,K] = epilogue(dy2[M,N] @ Wc[N,K])."""
+    """dx[M,K] = epilogue(dy2[M,N] @ Wc[N,K])   (W in its nn.Linear layout, outer-contiguous B)."""
     M, N = dy2.shape
     K = Wc.shape[1]
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
     k_gemm(dy2, Wc, dx, M, K, N, N, K, K, L.LAYOUT_K, L.LAYOUT_O, L.dt(dy2), act=act, aux=aux,
+           residual=residual)
+    return dx
+
+
+def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None):
+    """dx[M,K] = epilogue(dy2[M,N] @ Wt[K,N]^T) with the transposed weight copy: both operands
+    reduction-contiguous -> the direct-to-LDS GEMM path."""
+    M, N = dy2.shape
+    K = Wt.shape[0]
+    dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
+    k_gemm(dy2, Wt, dx, M, K, N, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.dt(dy2), act=act, aux=aux,
            residual=residual)
     return dx
 
@@ -421,16 +456,17 @@ class LinearFn(torch.autograd.Function):
         ctx.sink = _is_param(weight) and (bias is None or _is_param(bias))
         if ctx.sink:
             _use(weight, bias)
-        ctx.save_for_backward(x2, Wc, aux)
+        Wt = packed_t((weight,), x2.dtype) if ctx.needs_input_grad[0] else None
+        ctx.save_for_backward(x2, Wt, aux)
         return y.view(*x.shape[:-1], Wc.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, Wc, aux = ctx.saved_tensors
+        x2, Wt, aux = ctx.saved_tensors
         weight, bias = ctx.params
         dy2 = _as2d(dy)
         dz = dy2 if ctx.act == L.ACT_NONE else k_act_bwd(dy2, aux, ctx.act)
-        dx = k_dgrad(dz, Wc).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = k_dgrad_t(dz, Wt).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.sink:
             acc_linear_grads(dz, x2, weight, bias)
@@ -578,15 +614,15 @@ class SelfAttentionFn(torch.autograd.Function):
         ctx.dims, ctx.drop = (S, Lq, H, D), drop_p
         ctx.params = (wq, bq, wk, bk, wv, bv)
         _use(*ctx.params)
-        ctx.save_for_backward(x2, Wqkv, qkv, probs)
+        ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), qkv, probs)
         return ctxt.view(S, Lq, D)
 
     @staticmethod
     def backward(ctx, dctx):
-        x2, Wqkv, qkv, probs = ctx.saved_tensors
+        x2, Wqkv_t, qkv, probs = ctx.saved_tensors
         S, Lq, H, D = ctx.dims
         dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop)
-        dx = k_dgrad(dqkv, Wqkv).view(S, Lq, D) if ctx.needs_input_grad[0] else None
+        dx = k_dgrad_t(dqkv, Wqkv_t).view(S, Lq, D) if ctx.needs_input_grad[0] else None
         _qkv_bwd(dqkv, x2, ctx.params, D)
         return (dx,) + (None,) * 9
 
@@ -604,19 +640,19 @@ class ProjResLnFn(torch.autograd.Function):
         ctx.hshape, ctx.rshape = h.shape, res.shape
         ctx.params = (w, b, gamma, beta)
         _use(*ctx.params)
-        ctx.save_for_backward(h2, Wc, y, mean, rstd, gamma.detach())
+        ctx.save_for_backward(h2, packed_t((w,), h2.dtype), y, mean, rstd, gamma.detach())
         return out.view(res.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        h2, Wc, y, mean, rstd, gamma = ctx.saved_tensors
+        h2, Wt, y, mean, rstd, gamma = ctx.saved_tensors
         w, b, gp, bp = ctx.params
         dgd, dbd = ln_param_dsts(gp, bp)
         dy, dyd, _, _ = k_ln_bwd(y, _as2d(dout), gamma, mean, rstd, drop_in=ctx.drop, dgamma=dgd,
                                  dbeta=dbd, grad_beta=1.0, want_params=False)
         ln_params_done(gp, bp)
         acc_linear_grads(dyd, h2, w, b)
-        dh = k_dgrad(dyd, Wc).view(ctx.hshape)
+        dh = k_dgrad_t(dyd, Wt).view(ctx.hshape)
         return (dh, dy.view(ctx.rshape)) + (None,) * 6
 
 
@@ -637,12 +673,13 @@ class AttnBlockFn(torch.autograd.Function):
         ctx.dims, ctx.drops = (S, Lq, H, D), (drop_attn, drop_hid)
         ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1)
         _use(*ctx.params)
-        ctx.save_for_backward(x2, Wqkv, Wo, qkv, probs, ctxt, y1, mean, rstd, g1.detach())
+        ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), packed_t((wo,), x2.dtype), qkv, probs,
+                              ctxt, y1, mean, rstd, g1.detach())
         return a.view(S, Lq, D)
 
     @staticmethod
     def backward(ctx, da):
-        x2, Wqkv, Wo, qkv, probs, ctxt, y1, mean, rstd, g1 = ctx.saved_tensors
+        x2, Wqkv_t, Wo_t, qkv, probs, ctxt, y1, mean, rstd, g1 = ctx.saved_tensors
         S, Lq, H, D = ctx.dims
         drop_attn, drop_hid = ctx.drops
         wq, bq, wk, bk, wv, bv, wo, bo, g1p, b1p = ctx.params
@@ -651,10 +688,10 @@ class AttnBlockFn(torch.autograd.Function):
                                    dbeta=dbd, grad_beta=1.0, want_params=False)
         ln_params_done(g1p, b1p)
         acc_linear_grads(dy1d, ctxt, wo, bo)
-        dctx = k_dgrad(dy1d, Wo)
+        dctx = k_dgrad_t(dy1d, Wo_t)
         dqkv = k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=drop_attn)
         _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
-        dx = k_dgrad(dqkv, Wqkv, residual=dy1).view(S, Lq, D)      # + residual-path gradient, fused
+        dx = k_dgrad_t(dqkv, Wqkv_t, residual=dy1).view(S, Lq, D)  # + residual-path gradient, fused
         return (dx,) + (None,) * 15
 
 
@@ -674,19 +711,20 @@ class FfnBlockFn(torch.autograd.Function):
         ctx.drop, ctx.shp = drop_hid, shp
         ctx.params = (w1, b1, w2, b2, g2, bt2)
         _use(*ctx.params)
-        ctx.save_for_backward(a2, W1, W2, u, hg, y2, mean, rstd, g2.detach())
+        ctx.save_for_backward(a2, packed_t((w1,), a2.dtype), packed_t((w2,), a2.dtype), u, hg, y2, mean,
+                              rstd, g2.detach())
         return out.view(shp)
 
     @staticmethod
     def backward(ctx, dout):
-        a2, W1, W2, u, hg, y2, mean, rstd, g2 = ctx.saved_tensors
+        a2, W1_t, W2_t, u, hg, y2, mean, rstd, g2 = ctx.saved_tensors
         w1, b1, w2, b2, g2p, bt2p = ctx.params
         dgd, dbd = ln_param_dsts(g2p, bt2p)
         dy2, dy2d, _, _ = k_ln_bwd(y2, _as2d(dout), g2, mean, rstd, drop_in=ctx.drop, dgamma=dgd,
                                    dbeta=dbd, grad_beta=1.0, want_params=False)
         ln_params_done(g2p, bt2p)
         acc_linear_grads(dy2d, hg, w2, b2)
-        du = k_dgrad(dy2d, W2, act=L.ACT_GELU_BWD, aux=u)           # * gelu'(u), fused
+        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u)       # * gelu'(u), fused
         acc_linear_grads(du, a2, w1, b1)
-        da = k_dgrad(du, W1, residual=dy2).view(ctx.shp)            # + residual-path gradient, fused
+        da = k_dgrad_t(du, W1_t, residual=dy2).view(ctx.shp)        # + residual-path gradient, fused
         return (da,) + (None,) * 8

@@ -83,6 +83,7 @@ int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
 /* Per-launch timing of hero_gemm with HIP events recorded on the launch stream (bench.py's
  * roofline leg; off by default, never enable inside graph capture).
  * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout. hero_prof_read synchronises. */
+int hero_gemm_force_config(int cfg); /* tuning hook: 0 128x128, 1 128x256, 2 256x256, -1 heuristic */
 int hero_prof_enable(int on);
 int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches);
 
@@ -180,6 +181,9 @@ int hero_scatter_add_rows(const void* src, const int32_t* idx, void* dst_a, void
 /* ------------------------------------------------------------------------------------------ */
 /* dst <- (dst_dtype) src, n elements (fp32 master weights -> compute copies, outputs -> fp32). */
 int hero_cast(const void* src, void* dst, size_t n, int src_dtype, int dst_dtype, hero_stream_t stream);
+/* dst[c * ldd + r] <- (dst_dtype) src[r * cols + c]: transposed compute copies of the fp32 master
+ * weights, so that dgrad (dY W) also runs with both operands reduction-contiguous. */
+int hero_transpose_cast(const float* src, void* dst, int rows, int cols, int ldd, int dst_dtype, hero_stream_t stream);
 /* dx <- dy * (y > 0) — F.relu backward (model/layers.py:92).                                   */
 int hero_relu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, hero_stream_t stream);
 /* dx <- dy * gelu_erf'(u) — backward of model/layers.py:16-25 outside the fused FFN block.     */

@@ -36,8 +36,8 @@ HERO_BASE = {  # config/hero_finetune.json
 }
 VFEAT = 4352
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
-SLOT_NAMES = {4: "gemm_kernel<bf16,K,K> (forward x W^T)", 5: "gemm_kernel<bf16,K,O> (dgrad dY W)",
-              7: "gemm_kernel<bf16,O,O> (wgrad dY^T X)", 6: "gemm_kernel<bf16,O,K>"}
+SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (K-contiguous operands: forward x W^T and dgrad dY (W^T)^T)",
+              5: "gemm_kernel<bf16,K,O>", 7: "gemm_kernel<bf16,O,O> (wgrad dY^T X)", 6: "gemm_kernel<bf16,O,K>"}
 
 
 def algorithmic_flops_per_video(sh):
@@ -165,9 +165,22 @@ def main():
             slot, ms, fl, n = best
             ach = fl / (ms * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS if slot >= 4 else 157.3
+            traffic, tsrc = None, None
+            try:                                   # HBM bytes per launch from the committed PMC passes
+                pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+                pm = json.load(open(pj))
+                want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
+                        7: "gemm_kernel<unsigned short, 1, 1"}.get(slot)
+                hits = [v for k, v in pm.items() if want and want in k]
+                if hits:
+                    tot = sum(h["launches"] for h in hits)
+                    traffic = sum(h["hbm_bytes_per_launch_corrected"] * h["launches"] for h in hits) / tot
+                    tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+            except Exception:
+                pass
             roof = {"bound": "mfma", "kernel": SLOT_NAMES.get(slot, "gemm slot %d" % slot),
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "launches": n,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "launches": n,
                     "avg_launch_us": round(ms * 1e3 / n, 2),
                     "flops_per_launch": fl / n}
     elif world > 1:

@@ -583,8 +583,11 @@ static int launch(GemmArgs g, hipStream_t s) {
 // 256x256 tile wins ~5 % on the largest K-contiguous problems only.
 static int pick_cfg(int M, int N, int split, bool k_contig) {
   if (g_force_cfg >= 0) return g_force_cfg;
-  if (k_contig && split == 1 && (long long)((M + 255) / 256) * ((N + 255) / 256) >= 256) return 2;
-  return 0;
+  if (!k_contig || split != 1) return 0;
+  // one 256x256 workgroup per CU: only worth it when the tiles fill whole rounds of the 256 CUs
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const long long rounds = (tiles + 255) / 256;
+  return (tiles >= 256 && tiles * 10 >= rounds * 256 * 9) ? 2 : 0;
 }
 
 static int g_use_glds = 1;   // tuning hook

@@ -49,7 +49,7 @@ class LnBwd(C.Structure):
                 ("dx_dropped", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("grad_beta", C.c_float), ("workspace", C.c_void_p),
                 ("rows", C.c_int), ("cols", C.c_int), ("x_dtype", C.c_int), ("dtype", C.c_int),
-                ("dropout_out", Dropout), ("dropout_in", Dropout)]
+                ("dropout_out", Dropout), ("dropout_in", Dropout), ("dbias_in", C.c_void_p)]
 
 
 class Attn(C.Structure):

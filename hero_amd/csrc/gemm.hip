@@ -454,6 +454,125 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) 
   gemm_epilogue<T, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad flavour (both operands OUTER-contiguous: dY[M, N_out], X[M, K_in], reduction over rows):
+// direct-to-LDS staging of the untransposed [64 k][128 outer] tiles + ds_read_b64_tr_b16 fragment
+// reads.  Measured lane map of the transpose read (tools/lab/trprobe.hip): in each 16-lane group
+// lane i receives column i (4 consecutive rows) of the 4 x 16 block whose 8-byte row segments are
+// addressed by the group's lanes (lane p -> row p>>2, columns 4*(p&3)..+3).  Two reads give the 8
+// consecutive k of one outer index = one 32x32x16 MFMA operand.  Swizzle: 16-B chunk index XOR
+// 4*(k&3) (applied on the source address of the DMA and on the read address) spreads the 4 rows of
+// a group over distinct bank ranges.  bf16 only, 128x128 tile, reduction length % 64 == 0.
+// ---------------------------------------------------------------------------------------------
+struct GldsStageO {
+  int goff[4];
+  int lrow0;
+  __device__ __forceinline__ void init(int ld, int col0, int ncols) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rsub = lane >> 4, cp = lane & 15;
+    lrow0 = wave * 16;
+    const int c = cp ^ (4 * rsub);                       // (k & 3) == rsub for every row this lane touches
+    const int oc = min(col0 + c * 8, ncols - 8) - col0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) goff[i] = (lrow0 + i * 4 + rsub) * ld + oc;
+  }
+  __device__ __forceinline__ void issue(const bf16_t* __restrict__ b, char* lds) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(b + goff[i], (__attribute__((address_space(3))) void*)(lds + (lrow0 + i * 4) * 256), 16, 0, 0);
+  }
+};
+
+// the 8 transpose reads of one k-step (2 A fragments + 2 B fragments, two halves each) + wait
+__device__ __forceinline__ void tr_frags(unsigned a0, unsigned a1, unsigned b0, unsigned b1, int ks, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) {
+  uint2 r0, r1, r2, r3, r4, r5, r6, r7;
+  const unsigned o = ks * 4096;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %2, %9\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %4, %10\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %6, %11\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:1024\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+      : "v"(a0 + o), "v"(a1 + o), "v"(b0 + o), "v"(b1 + o)
+      : "memory");
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 t;
+  t = u32x4{r0.x, r0.y, r1.x, r1.y}; a[0] = __builtin_bit_cast(bf16x8_t, t);
+  t = u32x4{r2.x, r2.y, r3.x, r3.y}; a[1] = __builtin_bit_cast(bf16x8_t, t);
+  t = u32x4{r4.x, r4.y, r5.x, r5.y}; b[0] = __builtin_bit_cast(bf16x8_t, t);
+  t = u32x4{r6.x, r6.y, r7.x, r7.y}; b[1] = __builtin_bit_cast(bf16x8_t, t);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_glds_tr_kernel(GemmArgs g) {
+  typedef Cfg<2, 2, 2, 2> CF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileCoord tc = tile_coord<CF>(g);
+  const int m0 = tc.m0, n0 = tc.n0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow0 = wm * 64, brow0 = wn * 64;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  GldsStageO sa, sb;
+  sa.init(g.lda, m0, g.M);
+  sb.init(g.ldb, n0, g.N);
+  const bf16_t* pa = static_cast<const bf16_t*>(g.A) + (size_t)tc.kbeg * g.lda + m0;
+  const bf16_t* pb = static_cast<const bf16_t*>(g.B) + (size_t)tc.kbeg * g.ldb + n0;
+  const int nk = (tc.kend - tc.kbeg) / 64;
+
+  // per-lane read offsets inside a tile image [64 k][256 B]
+  const int p = lane & 15, gq = (lane >> 4) & 1, kg = lane >> 5;
+  unsigned fo[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int col = (f < 2 ? arow0 : brow0) + (f & 1) * 32 + gq * 16 + 4 * (p & 3);
+    fo[f] = (kg * 8 + (p >> 2)) * 256 + ((((col >> 3) ^ (4 * (p >> 2))) << 4) | ((col & 7) * 2));
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  if (nk > 0) {
+    sa.issue(pa, smem);
+    sb.issue(pb, smem + 16384);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned cur = lds0 + (kt & 1) * 32768;
+    char* nxt = smem + ((kt + 1) & 1) * 32768;
+    if (kt + 1 < nk) {
+      pa += (size_t)64 * g.lda;
+      pb += (size_t)64 * g.ldb;
+      sa.issue(pa, nxt);
+      sb.issue(pb, nxt + 16384);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t a[2], b[2];
+      tr_frags(cur + fo[0], cur + fo[1], cur + 16384 + fo[2], cur + 16384 + fo[3], ks, a, b);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue<bf16_t, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
+}
+
 template <typename T, int ALAY, int BLAY, typename CF>
 __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -623,8 +742,42 @@ static int launch_glds(GemmArgs g, hipStream_t s) {
   return check_launch("hero_gemm(glds)");
 }
 
+static int launch_glds_tr(GemmArgs g, hipStream_t s) {
+  typedef Cfg<2, 2, 2, 2> CF;
+  g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
+  g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
+  const int split = g.epi.split_k > 1 ? g.epi.split_k : 1;
+  const int grid = g.tiles_m * g.tiles_n * split;
+  ProfSlot* ps = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof_on) {
+    ps = &g_prof[7];
+    if (ps->flops.size() < 16384 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      (void)hipEventRecord(e0, s);
+    } else {
+      ps = nullptr;
+    }
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_glds_tr_kernel, dim3(grid), dim3(256), 65536, s, g);
+  if (ps) {
+    (void)hipEventRecord(e1, s);
+    ps->ev.push_back(e0);
+    ps->ev.push_back(e1);
+    ps->flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
+  }
+  return check_launch("hero_gemm(glds_tr)");
+}
+
 template <typename T, int AL, int BL>
 static int launch_cfg(const GemmArgs& g, int cfg, hipStream_t s) {
+  if (AL == HERO_LAYOUT_O && BL == HERO_LAYOUT_O && sizeof(T) == 2 && g_use_glds && g.K > 0 && g.K % 64 == 0 &&
+      g.k_per_split % 64 == 0)
+    return launch_glds_tr(g, s);
   if (AL == HERO_LAYOUT_K && BL == HERO_LAYOUT_K && g_use_glds && g.K > 0 && g.K % Tr<T>::BK == 0 &&
       g.k_per_split % Tr<T>::BK == 0) {
     if (cfg == 2) return launch_glds<T, Cfg256>(g, s);

@@ -136,8 +136,126 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(HeroLnBwd a) {
   }
 }
 
+// Fused backward for rows <= 1024 wide: dx (and dx * mask_in) as above, PLUS per-workgroup partial
+// sums of dgamma = sum dy*xhat, dbeta = sum dy and dbias_in = sum dx*mask_in (the bias gradient of
+// the linear layer that feeds this LayerNorm) in the same pass over x and dy.  Each wave walks rows
+// grid-stride and keeps the column partials in registers; one LDS reduction per workgroup writes
+// partial[block][3][cols]; colred_final3_kernel folds the partials (deterministic, no atomics).
+template <typename TX, typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(HeroLnBwd a, float* partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];       // [4 waves][3][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cols = a.cols;
+  DropCtx dout(a.dropout_out), din(a.dropout_in);
+  float4 ag[VPL], ab[VPL], ai[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) ag[i] = ab[i] = ai[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float inv = 1.f / (float)cols;
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    const TX* x = static_cast<const TX*>(a.x) + (size_t)row * cols;
+    const T* dy = static_cast<const T*>(a.dy) + (size_t)row * cols;
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    float4 xh[VPL], g[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      g[i] = xh[i];
+      if (c < cols) {
+        const float4 xv = V4<TX>::ld(x + c);
+        float4 d = V4<T>::ld(dy + c);
+        if (dout.on()) {
+          const float4 m = dout.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
+          d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+        }
+        const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c);
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) * inv;
+    s2 = wave_sum(s2) * inv;
+    T* dx = a.dx ? static_cast<T*>(a.dx) + (size_t)row * cols : nullptr;
+    T* dxd = a.dx_dropped ? static_cast<T*>(a.dx_dropped) + (size_t)row * cols : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < cols) {
+        float4 o;
+        o.x = rstd * (g[i].x - s1 - xh[i].x * s2);
+        o.y = rstd * (g[i].y - s1 - xh[i].y * s2);
+        o.z = rstd * (g[i].z - s1 - xh[i].z * s2);
+        o.w = rstd * (g[i].w - s1 - xh[i].w * s2);
+        if (dx) V4<T>::st(dx + c, o);
+        if (din.on()) {
+          const float4 m = din.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
+          o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+        }
+        if (dxd) V4<T>::st(dxd + c, o);
+        ai[i].x += o.x; ai[i].y += o.y; ai[i].z += o.z; ai[i].w += o.w;
+      }
+    }
+  }
+  // ---- workgroup reduction of the three column partials
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      *reinterpret_cast<float4*>(red + ((size_t)(wave * 3 + 0)) * cols + c) = ag[i];
+      *reinterpret_cast<float4*>(red + ((size_t)(wave * 3 + 1)) * cols + c) = ab[i];
+      *reinterpret_cast<float4*>(red + ((size_t)(wave * 3 + 2)) * cols + c) = ai[i];
+    }
+  }
+  __syncthreads();
+  const int n4 = 3 * (cols >> 2);
+  for (int q = threadIdx.x; q < n4; q += 256) {
+    const int k = q / (cols >> 2), c = (q - k * (cols >> 2)) * 4;
+    float4 v = *reinterpret_cast<const float4*>(red + (size_t)k * cols + c);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 u = *reinterpret_cast<const float4*>(red + ((size_t)(w * 3 + k)) * cols + c);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + k) * cols + c) = v;
+  }
+}
+
+// out_k[c] = beta*out_k[c] + sum_b partial[b][k][c] for k = 0..2 (outputs may be NULL)
+__global__ __launch_bounds__(256) void colred_final3_kernel(const float* partial, float* o0, float* o1, float* o2, int cols,
+                                                            int nblocks, float beta) {
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  __shared__ float red[4][16];
+  const int wave = threadIdx.x >> 6;
+  float* outs[3] = {o0, o1, o2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!outs[k]) continue;                       // uniform
+    float s = 0.f;
+    if (c < cols)
+      for (int b = kl; b < nblocks; b += 16) s += partial[((size_t)b * 3 + k) * cols + c];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((threadIdx.x & 63) < 16) red[wave][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < cols) {
+      s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+      outs[k][c] = (beta != 0.f ? beta * outs[k][c] : 0.f) + s;
+    }
+    __syncthreads();
+  }
+}
+
 // partial column sums over a chunk of rows.  pb[chunk][c] = sum dy_eff ; pg[chunk][c] = sum dy_eff*xhat
 struct ColRed {
+  float* og;          // atomic mode: accumulate straight into the outputs (beta == 1), no second pass
+  float* ob;
+  int atomic;
   const void* x;      // [rows, cols] TX or null
   const void* dy;     // [rows, ld]  T
   const float* mean;
@@ -186,8 +304,13 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRed a) {
       sg.x += g2.x; sg.y += g2.y; sg.z += g2.z; sg.w += g2.w;
       sb.x += b2.x; sb.y += b2.y; sb.z += b2.z; sb.w += b2.w;
     }
-    if (a.pg) *reinterpret_cast<float4*>(a.pg + (size_t)chunk * a.cols + c) = sg;
-    *reinterpret_cast<float4*>(a.pb + (size_t)chunk * a.cols + c) = sb;
+    if (a.atomic) {
+      if (a.og) { atomicAdd(a.og + c, sg.x); atomicAdd(a.og + c + 1, sg.y); atomicAdd(a.og + c + 2, sg.z); atomicAdd(a.og + c + 3, sg.w); }
+      if (a.ob) { atomicAdd(a.ob + c, sb.x); atomicAdd(a.ob + c + 1, sb.y); atomicAdd(a.ob + c + 2, sb.z); atomicAdd(a.ob + c + 3, sb.w); }
+    } else {
+      if (a.pg) *reinterpret_cast<float4*>(a.pg + (size_t)chunk * a.cols + c) = sg;
+      *reinterpret_cast<float4*>(a.pb + (size_t)chunk * a.cols + c) = sb;
+    }
   }
 }
 
@@ -237,9 +360,12 @@ static int run_colred(const void* x, const void* dy, const float* mean, const fl
   const int nchunks = chunking(rows, &a.rows_per_chunk);
   a.pb = static_cast<float*>(ws);
   a.pg = x ? a.pb + (size_t)nchunks * cols : nullptr;
+  a.atomic = 0;   // (fp32 atomics straight into the outputs were measured 3x SLOWER: 256-way contention)
+  a.og = x ? og : nullptr;
+  a.ob = ob;
   hipLaunchKernelGGL((colred_kernel<TX, T>), dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, a);
   int rc = check_launch("colred");
-  if (rc) return rc;
+  if (rc || a.atomic) return rc;
   hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
                      nchunks, beta);
   return check_launch("colred_final");
@@ -284,7 +410,7 @@ extern "C" int hero_layernorm_fwd(const HeroLnFwd* a, hero_stream_t stream) {
 
 extern "C" size_t hero_layernorm_bwd_workspace_bytes(int rows, int cols) {
   (void)rows;
-  return (size_t)256 * (size_t)cols * 2 * sizeof(float);
+  return (size_t)512 * (size_t)cols * 3 * sizeof(float);
 }
 extern "C" size_t hero_colsum_workspace_bytes(int rows, int cols) {
   (void)rows;
@@ -297,6 +423,30 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
   if (a->rows <= 0) return HERO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int xd = a->x_dtype, d = a->dtype;
+  const bool want_params = a->dgamma || a->dbeta || a->dbias_in;
+  if (want_params) HERO_REQUIRE(a->workspace, "hero_layernorm_bwd: workspace required for parameter gradients");
+  // ---- fused single pass (rows up to 1024 wide)
+  if (want_params && (a->dx || a->dx_dropped || a->dbias_in) && a->cols <= 1024) {
+    int nblk = (a->rows + 3) / 4;
+    if (nblk > 512) nblk = 512;
+    float* partial = static_cast<float*>(a->workspace);
+    const size_t lds = (size_t)4 * 3 * a->cols * sizeof(float);
+    const dim3 grid(nblk), block(256);
+#define CALLF(V)                                                                                                              \
+  if (xd == HERO_F32 && d == HERO_F32) hipLaunchKernelGGL((ln_bwd_fused_kernel<float, float, V>), grid, block, lds, s, *a, partial);          \
+  else if (xd == HERO_F32 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_fused_kernel<float, bf16_t, V>), grid, block, lds, s, *a, partial);   \
+  else if (xd == HERO_BF16 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_fused_kernel<bf16_t, bf16_t, V>), grid, block, lds, s, *a, partial); \
+  else { set_error("hero_layernorm_bwd: unsupported dtypes x=%d dy=%d", xd, d); return HERO_ERR_UNSUPPORTED; }
+    const int need = (a->cols + 255) / 256;
+    if (need <= 1) { CALLF(1); } else if (need <= 2) { CALLF(2); } else if (need <= 3) { CALLF(3); } else { CALLF(4); }
+#undef CALLF
+    int rc = check_launch("hero_layernorm_bwd(fused)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 15) / 16), dim3(256), 0, s, partial, a->dgamma, a->dbeta, a->dbias_in,
+                       a->cols, nblk, a->grad_beta);
+    return check_launch("hero_layernorm_bwd(final3)");
+  }
+  HERO_REQUIRE(!a->dbias_in, "hero_layernorm_bwd: dbias_in needs cols <= 1024");
   if (a->dx || a->dx_dropped) {
     const dim3 grid((a->rows + 3) / 4), block(256);
 #define CALL(V)                                                                                                      \
@@ -310,7 +460,6 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
     if (rc) return rc;
   }
   if (a->dgamma || a->dbeta) {
-    HERO_REQUIRE(a->workspace, "hero_layernorm_bwd: workspace required for dgamma/dbeta");
     if (xd == HERO_F32 && d == HERO_F32)
       return run_colred<float, float>(a->x, a->dy, a->mean, a->rstd, a->dgamma, a->dbeta, a->rows, a->cols, a->cols, a->grad_beta, a->dropout_out, a->workspace, s);
     if (xd == HERO_F32 && d == HERO_BF16)

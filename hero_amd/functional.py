@@ -330,7 +330,7 @@ def ln_params_done(gamma_p, beta_p):
 
 
 def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_out=None,
-             drop_in=None, dgamma=None, dbeta=None, grad_beta=0.0):
+             drop_in=None, dgamma=None, dbeta=None, grad_beta=0.0, dbias_in=None):
     """dgamma/dbeta given: accumulate into them with grad_beta (the gradient sink path)."""
     rows, cols = dy2.shape
     dev = dy2.device
@@ -340,13 +340,14 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
     if want_params and dg is None and db is None:
         dg = torch.empty((cols,), dtype=torch.float32, device=dev)
         db = torch.empty((cols,), dtype=torch.float32, device=dev)
-    ws = _workspace(512 * cols, dev) if (dg is not None or db is not None) else None
+    ws = _workspace(1536 * cols, dev) if (dg is not None or db is not None or dbias_in is not None) else None
     a = L.LnBwd()
     a.x, a.dy, a.gamma, a.mean, a.rstd = L.ptr(x2), L.ptr(dy2), L.ptr(gamma), L.ptr(mean), L.ptr(rstd)
     a.dx, a.dx_dropped, a.dgamma, a.dbeta = L.ptr(dx), L.ptr(dxd), L.ptr(dg), L.ptr(db)
     a.grad_beta, a.workspace = grad_beta, L.ptr(ws)
     a.rows, a.cols, a.x_dtype, a.dtype = rows, cols, L.dt(x2), L.dt(dy2)
     a.dropout_out, a.dropout_in = _d(drop_out), _d(drop_in)
+    a.dbias_in = L.ptr(dbias_in)
     L.check(L.lib().hero_layernorm_bwd(C.byref(a), L.stream()))
     return dx, (dxd if dxd is not None else dx), dg, db
 
@@ -648,10 +649,14 @@ class ProjResLnFn(torch.autograd.Function):
         h2, Wt, y, mean, rstd, gamma = ctx.saved_tensors
         w, b, gp, bp = ctx.params
         dgd, dbd = ln_param_dsts(gp, bp)
+        fuse_b = b.requires_grad and y.shape[1] <= 1024
         dy, dyd, _, _ = k_ln_bwd(y, _as2d(dout), gamma, mean, rstd, drop_in=ctx.drop, dgamma=dgd,
-                                 dbeta=dbd, grad_beta=1.0, want_params=False)
+                                 dbeta=dbd, grad_beta=1.0, want_params=False,
+                                 dbias_in=SINK.dst(b) if fuse_b else None)
         ln_params_done(gp, bp)
-        acc_linear_grads(dyd, h2, w, b)
+        if fuse_b:
+            SINK.done(b)
+        acc_linear_grads(dyd, h2, w, None if fuse_b else b)
         dh = k_dgrad_t(dyd, Wt).view(ctx.hshape)
         return (dh, dy.view(ctx.rshape)) + (None,) * 6
 
@@ -684,10 +689,14 @@ class AttnBlockFn(torch.autograd.Function):
         drop_attn, drop_hid = ctx.drops
         wq, bq, wk, bk, wv, bv, wo, bo, g1p, b1p = ctx.params
         dgd, dbd = ln_param_dsts(g1p, b1p)
+        fuse_b = bo.requires_grad and D <= 1024
         dy1, dy1d, _, _ = k_ln_bwd(y1, _as2d(da), g1, mean, rstd, drop_in=drop_hid, dgamma=dgd,
-                                   dbeta=dbd, grad_beta=1.0, want_params=False)
+                                   dbeta=dbd, grad_beta=1.0, want_params=False,
+                                   dbias_in=SINK.dst(bo) if fuse_b else None)
         ln_params_done(g1p, b1p)
-        acc_linear_grads(dy1d, ctxt, wo, bo)
+        if fuse_b:
+            SINK.done(bo)
+        acc_linear_grads(dy1d, ctxt, wo, None if fuse_b else bo)
         dctx = k_dgrad_t(dy1d, Wo_t)
         dqkv = k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=drop_attn)
         _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
@@ -720,10 +729,14 @@ class FfnBlockFn(torch.autograd.Function):
         a2, W1_t, W2_t, u, hg, y2, mean, rstd, g2 = ctx.saved_tensors
         w1, b1, w2, b2, g2p, bt2p = ctx.params
         dgd, dbd = ln_param_dsts(g2p, bt2p)
+        fuse_b = b2.requires_grad and y2.shape[1] <= 1024
         dy2, dy2d, _, _ = k_ln_bwd(y2, _as2d(dout), g2, mean, rstd, drop_in=ctx.drop, dgamma=dgd,
-                                   dbeta=dbd, grad_beta=1.0, want_params=False)
+                                   dbeta=dbd, grad_beta=1.0, want_params=False,
+                                   dbias_in=SINK.dst(b2) if fuse_b else None)
         ln_params_done(g2p, bt2p)
-        acc_linear_grads(dy2d, hg, w2, b2)
+        if fuse_b:
+            SINK.done(b2)
+        acc_linear_grads(dy2d, hg, w2, None if fuse_b else b2)
         du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u)       # * gelu'(u), fused
         acc_linear_grads(du, a2, w1, b1)
         da = k_dgrad_t(du, W1_t, residual=dy2).view(ctx.shp)        # + residual-path gradient, fused

@@ -81,19 +81,29 @@ class HeroForPretraining(HeroModel):
                 self.lw_neg_q * loss_neg_q)
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _conv5(conv, x):
+        """nn.Conv1d(1, 1, k, padding=k//2, bias=False) on (N, 1, L) as unfold + dot: a handful of
+        elementwise launches instead of MIOpen's im2col/winograd pipeline for a 5-tap filter."""
+        k = conv.kernel_size[0]
+        if conv.stride[0] != 1:
+            return conv(x)
+        xp = F.pad(x, (k // 2, k // 2))
+        return (xp.unfold(-1, k, 1) * conv.weight.view(1, 1, 1, k)).sum(-1)
+
     def _get_st_ed_prob(self, modularized_query, context_feat2, context_mask, cross=False):
         query = self.video_query_linear(modularized_query)
         if cross:
             sim = torch.einsum("md,nld->mnl", query, context_feat2)
             n_q, n_c, ln = sim.shape
             flat = sim.reshape(n_q * n_c, 1, ln)
-            st = self.video_st_predictor(flat).view(n_q, n_c, ln)
-            ed = self.video_ed_predictor(flat).view(n_q, n_c, ln)
+            st = self._conv5(self.video_st_predictor, flat).view(n_q, n_c, ln)
+            ed = self._conv5(self.video_ed_predictor, flat).view(n_q, n_c, ln)
             context_mask = context_mask.unsqueeze(0)
         else:
             sim = torch.einsum("bd,bld->bl", query, context_feat2).unsqueeze(1)
-            st = self.video_st_predictor(sim).squeeze(1)
-            ed = self.video_ed_predictor(sim).squeeze(1)
+            st = self._conv5(self.video_st_predictor, sim).squeeze(1)
+            ed = self._conv5(self.video_ed_predictor, sim).squeeze(1)
         m = context_mask.to(st.dtype)
         return mask_logits(st, m), mask_logits(ed, m)
 

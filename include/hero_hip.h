@@ -127,6 +127,8 @@ typedef struct HeroLnBwd {
   int x_dtype, dtype;
   HeroDropout dropout_out; /* the forward's output dropout (applied to dy first)                */
   HeroDropout dropout_in;  /* dropout of the GEMM epilogue that produced x (for dx_dropped)     */
+  float* dbias_in;         /* optional [cols] (cols <= 1024): += sum_rows dx*mask(dropout_in) =     */
+                           /* bias gradient of the linear layer feeding this LN, same pass         */
 } HeroLnBwd;
 size_t hero_layernorm_bwd_workspace_bytes(int rows, int cols);
 int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream);

@@ -56,7 +56,8 @@ def test_gemm_forward_epilogues(HF, Lb, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (203, 136, 96), (515, 768, 3072), (4000, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (203, 136, 96), (515, 768, 3072), (4000, 768, 768),
+                                   (1024, 200, 328), (11520, 768, 768), (1920, 2304, 768)])
 def test_gemm_dgrad_wgrad(HF, Lb, dtype, M, N, K):
     """dgrad: dy[M,N] @ W[N,K]; wgrad: dy^T @ x (fp32 out, split-K atomics for large M)."""
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05)
@@ -189,6 +190,15 @@ def test_ln_bwd_dropout_consistency(HF, Lb):
     dy = rnd(M, N, seed=7)
     dx, dxd, _, _ = HF.k_ln_bwd(y, dy, g, mean, rstd, drop_in=drop)
     torch.testing.assert_close(dxd, dx * mask / 0.7, rtol=1e-5, atol=1e-6)
+    # fused pass: parameter gradients + the feeding linear's bias gradient, accumulated (beta = 1)
+    dg = torch.ones(N, device="cuda"); db = torch.full((N,), 2.0, device="cuda"); dbias = torch.full((N,), 3.0, device="cuda")
+    dx2, dxd2, _, _ = HF.k_ln_bwd(y, dy, g, mean, rstd, drop_in=drop, dgamma=dg, dbeta=db, grad_beta=1.0,
+                                  want_params=False, dbias_in=dbias)
+    torch.testing.assert_close(dx2, dx)
+    xh = (y - mean[:, None]) * rstd[:, None]
+    torch.testing.assert_close(dg, 1 + (dy * xh).sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db, 2 + dy.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dbias, 3 + dxd.sum(0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -16,8 +16,17 @@ __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WAVES_EU)))
 void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = N / 128;
+  const int tiles_n = N / 128, tiles_m = M / 128;
+#ifdef REMAP
+  int wg;
+  { const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc; }
+  const int per_group = 8 * tiles_n, group = wg / per_group, first_m = group * 8;
+  const int gsz = min(tiles_m - first_m, 8), in_group = wg - group * per_group;
+  const int pid_m = first_m + in_group % gsz, pid_n = in_group / gsz;
+#else
   const int pid_m = blockIdx.x / tiles_n, pid_n = blockIdx.x % tiles_n;
+#endif
   const int m0 = pid_m * 128, n0 = pid_n * 128;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
   f32x16_t acc[2][2];
@@ -82,7 +91,23 @@ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t*
 #endif
     __syncthreads();
   }
-#ifndef NO_EPI
+#if defined(EPI_LDS)
+  {
+    float* lc = (float*)smem;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+      const int col = wn * 64 + j * 32 + (lane & 31);
+      for (int r = 0; r < 16; ++r) lc[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 128 + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int c4 = (threadIdx.x & 31) * 4;
+    for (int it = 0; it < 16; ++it) {
+      const int row = (threadIdx.x >> 5) + it * 8;
+      const float4 v = *(const float4*)(lc + row * 128 + c4);
+      uint2 o; o.x = (__float_as_uint(v.x) >> 16) | (__float_as_uint(v.y) & 0xffff0000u); o.y = (__float_as_uint(v.z) >> 16) | (__float_as_uint(v.w) & 0xffff0000u);
+      *(uint2*)(C + (size_t)(m0 + row) * N + n0 + c4) = o;
+    }
+  }
+#elif !defined(NO_EPI)
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
     const int gn = n0 + wn * 64 + j * 32 + (lane & 31);
     for (int r = 0; r < 16; ++r) {

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +124,7 @@ def main():
     with open(cfg_path, "w") as f:
         json.dump(HERO_BASE, f)
     model = build_model(device, cfg_path)
-    trainer = TrainStep(model)
+    trainer = TrainStep(model, use_graph=(world == 1 and not args.no_graph))
     batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device)
     sh = SHAPES["D2"]
 
@@ -151,6 +152,7 @@ def main():
     roof = None
     if rank == 0:
         L.check(L.lib().hero_prof_enable(1))
+        trainer.use_graph = False                    # events cannot be recorded inside a replay
         for _ in range(args.profile_steps):
             trainer.micro_step(batch)
         torch.cuda.synchronize()
@@ -186,6 +188,7 @@ def main():
     elif world > 1:
         for _ in range(args.profile_steps):
             trainer.micro_step(batch)
+    launch_mode = "hipGraph replay" if (world == 1 and not args.no_graph) else "eager"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -204,7 +207,7 @@ def main():
                                    "32 videos x 60 frames, 15 subs x (4 frames + 20 tokens), 15-token query; "
                                    "vfeat 4352; fwd + VSM loss + bwd, all-reduce/clip/AdamW every 2nd micro-step)",
                        "global_batch": sh["videos"] * world, "parallelism": "dp%d" % world,
-                       "dropout": 0.1, "grad_accum": 2},
+                       "dropout": 0.1, "grad_accum": 2, "launch": launch_mode},
             "step_tflops": round(vps * fl_video / 1e12, 1),
             "step_frac_of_bf16_peak": round(vps * fl_video / 1e12 / world / BF16_PEAK_TFLOPS, 4),
             "final_loss": loss_val,

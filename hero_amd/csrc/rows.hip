@@ -197,10 +197,11 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
     const float clip = a.max_grad_norm / (norm + 1e-6f);
     if (clip < 1.f) gs *= clip;
   }
-  const float st = (float)(a.step - d.step_lag);
+  const float st = (float)((a.step_ptr ? *a.step_ptr : a.step) - d.step_lag);
+  const float lr = a.lr_ptr ? a.lr_ptr[d.group] : gr.lr;
   const float bc1 = 1.f - powf(gr.beta1, st), bc2 = 1.f - powf(gr.beta2, st);
-  const float step_size = gr.lr * sqrtf(bc2) / bc1;
-  const float decay = gr.lr * gr.weight_decay;
+  const float step_size = lr * sqrtf(bc2) / bc1;
+  const float decay = lr * gr.weight_decay;
   const bool vec = ((((uintptr_t)d.p | (uintptr_t)d.g | (uintptr_t)d.m | (uintptr_t)d.v) & 15) == 0);
   if (vec) {
     const size_t e4 = beg + ((end - beg) & ~(size_t)3);
@@ -382,7 +383,7 @@ extern "C" int hero_adamw(const HeroAdamW* a, hero_stream_t stream) {
 
 extern "C" int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream) {
   HERO_REQUIRE(a && a->descs && a->chunk_tensor && a->chunk_index, "hero_adamw_multi: null pointer");
-  HERO_REQUIRE(a->step >= 1, "hero_adamw_multi: step must be >= 1");
+  HERO_REQUIRE(a->step >= 1 || a->step_ptr, "hero_adamw_multi: step must be >= 1");
   if (a->n_chunks <= 0) return HERO_OK;
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(a->n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("hero_adamw_multi");

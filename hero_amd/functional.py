@@ -100,6 +100,14 @@ def clear_weight_cache():
     _WCACHE.clear()
 
 
+def refresh_weight_cache():
+    """Re-derive every cached compute copy from the current fp32 master weights NOW (used right
+    after an optimiser step inside a captured graph, so the next forward finds the cache valid)."""
+    for key, val in list(_WCACHE.items()):
+        _WCACHE[key] = (None, val[1], val[2])          # same buffer, signature invalidated
+        (packed_t if len(key) == 3 else packed)(val[2], key[1])
+
+
 def packed(params, dtype):
     """Row-concatenate fp32 parameters into one contiguous tensor of `dtype` (cached)."""
     params = tuple(params)
@@ -121,7 +129,7 @@ def packed(params, dtype):
         L.check(L.lib().hero_cast(L.ptr(p.detach().contiguous()), dst.data_ptr(), n, L.F32,
                                   L.dt(out), L.stream()))
         off += p.shape[0]
-    _WCACHE[key] = (sig, out)
+    _WCACHE[key] = (sig, out, params)
     return out
 
 
@@ -144,7 +152,7 @@ def packed_t(params, dtype):
                                             out.data_ptr() + off * out.element_size(), p.shape[0], kin,
                                             cols, L.dt(out), L.stream()))
         off += p.shape[0]
-    _WCACHE[key] = (sig, out)
+    _WCACHE[key] = (sig, out, params)
     return out
 
 

@@ -141,11 +141,11 @@ class HeroForPretraining(HeroModel):
         dev = query_context_scores.device
         if nv == 1:
             return torch.tensor(0, device=dev), torch.tensor(0, device=dev)
-        qi = torch.arange(nq, device=dev)
-        own = qi // per
-        pos = query_context_scores[qi, own]                          # (nq,)
-        masked = query_context_scores.clone()
-        masked[qi, own] = 999
+        own = torch.arange(nq, device=dev) // per                    # video of each query
+        is_pos = own.unsqueeze(1) == torch.arange(nv, device=dev).unsqueeze(0)
+        # (select/where instead of indexed assignment: no host sync, hipGraph-capturable)
+        pos = torch.where(is_pos, query_context_scores, torch.zeros_like(query_context_scores)).sum(1)
+        masked = torch.where(is_pos, torch.full_like(query_context_scores, 999), query_context_scores)
         if self.use_all_neg:
             neg_ctx = masked.sort(dim=1, descending=True)[0][:, 1:]
             l_ctx = self._weight_hard(self.get_ranking_loss(pos.view(nq, 1), neg_ctx))

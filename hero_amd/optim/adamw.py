@@ -65,7 +65,10 @@ class AdamW(Optimizer):
         return raw, t_ct, t_ci, len(ct)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_sumsq=None, max_grad_norm=0.0, grad_scale=1.0, skip=None):
+    def step(self, closure=None, grad_sumsq=None, max_grad_norm=0.0, grad_scale=1.0, skip=None,
+             step_tensor=None, lr_tensor=None):
+        """step_tensor (int32[1]) / lr_tensor (float32[8]) on the device override the host-side step
+        count and per-group learning rates — required when the step is captured in a hipGraph."""
         loss = closure() if closure is not None else None
         self._global_step += 1
         active = []
@@ -93,6 +96,7 @@ class AdamW(Optimizer):
             b1, b2 = group["betas"]
             a.groups[gi] = L.AdamWGroup(group["lr"], b1, b2, group["eps"], group["weight_decay"])
         a.step = self._global_step
+        a.step_ptr, a.lr_ptr = L.ptr(step_tensor), L.ptr(lr_tensor)
         a.grad_sumsq = L.ptr(grad_sumsq)
         a.max_grad_norm, a.grad_scale = max_grad_norm, grad_scale
         L.check(L.lib().hero_adamw_multi(C.byref(a), L.stream()))

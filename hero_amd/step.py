@@ -7,12 +7,15 @@
 
 MI355X-first differences: no host synchronisation inside the step (the reference calls .item() four
 times per micro-step), gradients live in one flat arena that is all-reduced in buckets while
-backward is still running, and clipping + averaging + AdamW are one kernel pass per tensor.
+backward is still running, clipping + averaging + AdamW are one kernel pass, and — for static
+shapes on one GPU — the whole micro-step (forward, loss, backward, optimiser) is captured once in
+a hipGraph and replayed, which removes the ~900 host-side launches per step.
 """
 from types import SimpleNamespace
 
 import torch
 
+from . import functional as HF
 from .optim import build_optimizer, get_lr_sched
 from .utils import distributed as D
 
@@ -23,7 +26,7 @@ TVR_OPTS = dict(  # config/train-tvr-8gpu.json
 
 
 class TrainStep:
-    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20):
+    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False):
         self.model = model
         self.opts = SimpleNamespace(**{**TVR_OPTS, **(opts or {})})
         self.task = task
@@ -32,26 +35,96 @@ class TrainStep:
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152
+        self.use_graph = use_graph and D.world_size() == 1
+        self._graphs = None
+        dev = next(model.parameters()).device
+        self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side optimiser step
+        self._lr_t = torch.zeros(8, dtype=torch.float32, device=dev)
 
-    def micro_step(self, batch):
-        """One forward+backward; optimiser step on accumulation boundaries. Returns the loss
-        tensor (device-resident, not synchronised)."""
-        accum = self.opts.gradient_accumulation_steps
-        boundary = (self.micro + 1) % accum == 0
-        self.arena.set_sync(boundary)
+    # ---- pieces ------------------------------------------------------------------------------------
+    def _fwd_bwd(self, batch):
+        HF.advance_seed()
         l_st_ed, l_ctx, l_q = self.model(batch, task=self.task, compute_loss=True)
         loss = (l_st_ed + l_ctx + l_q).mean()
         loss.backward()
+        return loss.detach()
+
+    def _optimise(self, device_state):
+        self.arena.finish()
+        untouched = [p for p in self.arena.params if p not in self.arena.touched]
+        sumsq = self.optimizer.grad_sumsq(self.arena.flat) if self.opts.grad_norm != -1 else None
+        if device_state:
+            self._step_t.add_(1)
+        self.optimizer.step(grad_sumsq=sumsq, max_grad_norm=float(self.opts.grad_norm),
+                            grad_scale=1.0 / D.world_size(), skip=set(untouched),
+                            step_tensor=self._step_t if device_state else None,
+                            lr_tensor=self._lr_t if device_state else None)
+        if device_state:
+            HF.refresh_weight_cache()
+        self.arena.zero()
+
+    def _set_lr(self):
+        self.global_step += 1
+        lr = get_lr_sched(self.global_step, self.opts)
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr                               # train_vcmr.py:248-249 (all groups)
+        return lr
+
+    # ---- eager -------------------------------------------------------------------------------------
+    def micro_step(self, batch):
+        """One forward+backward; optimiser step on accumulation boundaries. Returns the loss
+        tensor (device-resident, not synchronised)."""
+        if self.use_graph:
+            return self._graph_step(batch)
+        accum = self.opts.gradient_accumulation_steps
+        boundary = (self.micro + 1) % accum == 0
+        self.arena.set_sync(boundary)
+        loss = self._fwd_bwd(batch)
         self.micro += 1
         if boundary:
-            self.arena.finish()
-            self.global_step += 1
-            lr = get_lr_sched(self.global_step, self.opts)
-            for g in self.optimizer.param_groups:
-                g["lr"] = lr                       # train_vcmr.py:248-249 (all groups)
-            untouched = [p for p in self.arena.params if p not in self.arena.touched]
-            sumsq = self.optimizer.grad_sumsq(self.arena.flat) if self.opts.grad_norm != -1 else None
-            self.optimizer.step(grad_sumsq=sumsq, max_grad_norm=float(self.opts.grad_norm),
-                                grad_scale=1.0 / D.world_size(), skip=set(untouched))
-            self.arena.zero()
-        return loss.detach()
+            self._set_lr()
+            self._optimise(device_state=False)
+        return loss
+
+    # ---- hipGraph ------------------------------------------------------------------------------------
+    def _capture(self, batch):
+        """Warm up eagerly (all lazy state: kernel attributes, index maps, workspaces, optimiser
+        tables), then capture two graphs on the same static batch: plain micro-step and boundary
+        micro-step (with clip + AdamW + weight-copy refresh + gradient zeroing)."""
+        accum = self.opts.gradient_accumulation_steps
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(2 * accum):
+                self.arena.set_sync((i + 1) % accum == 0)
+                self._fwd_bwd(batch)
+                if (i + 1) % accum == 0:
+                    lr = self._set_lr()
+                    self._lr_t.fill_(lr)
+                    self._optimise(device_state=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.micro += 2 * accum
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            loss_a = self._fwd_bwd(batch)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            loss_b = self._fwd_bwd(batch)
+            self._optimise(device_state=True)
+        self._graphs = (ga, loss_a, gb, loss_b, batch)
+
+    def _graph_step(self, batch):
+        if self._graphs is None:
+            self._capture(batch)
+        ga, loss_a, gb, loss_b, static_batch = self._graphs
+        if batch is not static_batch:
+            raise RuntimeError("graph mode replays the captured batch buffers; copy new data into them")
+        accum = self.opts.gradient_accumulation_steps
+        boundary = (self.micro + 1) % accum == 0
+        self.micro += 1
+        if boundary:
+            self._lr_t.fill_(self._set_lr())        # stream-ordered scalar fill (no pinned-buffer race)
+            gb.replay()
+            return loss_b
+        ga.replay()
+        return loss_a

@@ -241,6 +241,8 @@ typedef struct HeroAdamWMulti {
   const float* grad_sumsq;
   float max_grad_norm;
   float grad_scale;
+  const int32_t* step_ptr; /* optional device scalar overriding `step` (hipGraph replays)      */
+  const float* lr_ptr;     /* optional device array [8] overriding groups[].lr                 */
 } HeroAdamWMulti;
 int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream);
 int hero_adamw_multi_chunk(void);

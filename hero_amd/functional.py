@@ -670,31 +670,43 @@ class ProjResLnFn(torch.autograd.Function):
 
 
 class AttnBlockFn(torch.autograd.Function):
-    """BertAttention (model/layers.py:217-222) as ONE node: a = LN(drop(MHA(x) Wo^T + bo) + x)."""
+    """BertAttention (model/layers.py:217-222) as ONE node: a = LN(drop(MHA(x) Wo^T + bo) + x).
+
+    `x` is [rows, D]; `segs` = ((S, L), ...) lists the sequence groups stacked along the rows
+    (sum S*L == rows).  Everything except the attention itself is row-wise, so several groups with
+    different lengths — e.g. HERO's subtitle rows (L = frames+tokens) and its query rows — share the
+    GEMM / LayerNorm launches and only the attention kernel is called per group."""
 
     @staticmethod
-    def forward(ctx, x, mask_add, H, eps, drop_attn, drop_hid, wq, bq, wk, bk, wv, bv, wo, bo, g1, b1):
-        S, Lq, D = x.shape
+    def forward(ctx, x, segs, masks, H, eps, drops_attn, drop_hid, wq, bq, wk, bk, wv, bv, wo, bo, g1, b1):
         x2 = _as2d(x)
+        D = x2.shape[1]
         Wqkv = packed((wq, wk, wv), x2.dtype)
         bqkv = packed((bq, bk, bv), torch.float32)
         Wo = packed((wo,), x2.dtype)
         qkv = k_linear(x2, Wqkv, bqkv)
-        ctxt, probs = k_attn_fwd(qkv, mask_add, S, Lq, H, drop=drop_attn)
+        ctxs, probs = [], []
+        r0 = 0
+        for (S, Lq), m, dr in zip(segs, masks, drops_attn):
+            c, p = k_attn_fwd(qkv[r0:r0 + S * Lq], m, S, Lq, H, drop=dr)
+            ctxs.append(c)
+            probs.append(p)
+            r0 += S * Lq
+        ctxt = ctxs[0] if len(ctxs) == 1 else torch.cat(ctxs, 0)
         y1 = k_linear(ctxt, Wo, bo.detach(), residual=x2, drop=drop_hid)
-        a, mean, rstd, _ = k_ln_fwd(y1, g1.detach(), b1.detach(), eps, y1.dtype, S * Lq, D)
-        ctx.dims, ctx.drops = (S, Lq, H, D), (drop_attn, drop_hid)
+        a, mean, rstd, _ = k_ln_fwd(y1, g1.detach(), b1.detach(), eps, y1.dtype, x2.shape[0], D)
+        ctx.meta = (segs, H, D, drops_attn, drop_hid, x.shape)
         ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1)
         _use(*ctx.params)
-        ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), packed_t((wo,), x2.dtype), qkv, probs,
-                              ctxt, y1, mean, rstd, g1.detach())
-        return a.view(S, Lq, D)
+        ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), packed_t((wo,), x2.dtype), qkv, ctxt, y1,
+                              mean, rstd, g1.detach(), *probs)
+        return a.view(x.shape)
 
     @staticmethod
     def backward(ctx, da):
-        x2, Wqkv_t, Wo_t, qkv, probs, ctxt, y1, mean, rstd, g1 = ctx.saved_tensors
-        S, Lq, H, D = ctx.dims
-        drop_attn, drop_hid = ctx.drops
+        x2, Wqkv_t, Wo_t, qkv, ctxt, y1, mean, rstd, g1 = ctx.saved_tensors[:9]
+        probs = ctx.saved_tensors[9:]
+        segs, H, D, drops_attn, drop_hid, xshape = ctx.meta
         wq, bq, wk, bk, wv, bv, wo, bo, g1p, b1p = ctx.params
         dgd, dbd = ln_param_dsts(g1p, b1p)
         fuse_b = bo.requires_grad and D <= 1024
@@ -706,10 +718,15 @@ class AttnBlockFn(torch.autograd.Function):
             SINK.done(bo)
         acc_linear_grads(dy1d, ctxt, wo, None if fuse_b else bo)
         dctx = k_dgrad_t(dy1d, Wo_t)
-        dqkv = k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=drop_attn)
+        dqs = []
+        r0 = 0
+        for (S, Lq), p, dr in zip(segs, probs, drops_attn):
+            dqs.append(k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr))
+            r0 += S * Lq
+        dqkv = dqs[0] if len(dqs) == 1 else torch.cat(dqs, 0)
         _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
-        dx = k_dgrad_t(dqkv, Wqkv_t, residual=dy1).view(S, Lq, D)  # + residual-path gradient, fused
-        return (dx,) + (None,) * 15
+        dx = k_dgrad_t(dqkv, Wqkv_t, residual=dy1).view(xshape)    # + residual-path gradient, fused
+        return (dx,) + (None,) * 16
 
 
 class FfnBlockFn(torch.autograd.Function):

@@ -146,12 +146,16 @@ class BertAttention(nn.Module):
         x = HF.cast(input_tensor, HF.compute_dtype())
         S, Lq, _ = x.shape
         m = HF.as_mask_add(attention_mask, S, Lq)
+        return (self.forward_rows(x, ((S, Lq),), (m,)),)
+
+    def forward_rows(self, x, segs, masks):
+        """x: [rows, D] or (S, L, D) holding the sequence groups `segs` = ((S, L), ...) stacked along
+        the rows; masks: additive fp32 [S, L] per group."""
         so, o = self.self, self.output
-        a = HF.AttnBlockFn.apply(
-            x, m, so.num_attention_heads, o.LayerNorm.eps, _drop(so.dropout, x.device),
-            _drop(o.dropout, x.device), *so.qkv_params(), o.dense.weight, o.dense.bias,
-            o.LayerNorm.weight, o.LayerNorm.bias)
-        return (a,)
+        return HF.AttnBlockFn.apply(
+            x, tuple(segs), tuple(masks), so.num_attention_heads, o.LayerNorm.eps,
+            tuple(_drop(so.dropout, x.device) for _ in segs), _drop(o.dropout, x.device),
+            *so.qkv_params(), o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias)
 
 
 class BertIntermediate(nn.Module):
@@ -184,11 +188,16 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None):
         a = self.attention(hidden_states, attention_mask, head_mask)[0]
+        return (self._ffn(a),)
+
+    def _ffn(self, a):
         o = self.output
-        out = HF.FfnBlockFn.apply(a, o.LayerNorm.eps, _drop(o.dropout, a.device),
-                                  self.intermediate.dense.weight, self.intermediate.dense.bias,
-                                  o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias)
-        return (out,)
+        return HF.FfnBlockFn.apply(a, o.LayerNorm.eps, _drop(o.dropout, a.device),
+                                   self.intermediate.dense.weight, self.intermediate.dense.bias,
+                                   o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias)
+
+    def forward_rows(self, x, segs, masks):
+        return self._ffn(self.attention.forward_rows(x, segs, masks))
 
 
 class BertPooler(nn.Module):
@@ -221,6 +230,25 @@ class BertEncoder(nn.Module):
         for layer in self.layer:
             x = layer(x, m4, None)[0]
         return (x,)
+
+    def forward_multi(self, hidden_list, mask_list):
+        """Run several independent sequence groups (tensors (S_i, L_i, D) + their (S_i, L_i) 0/1
+        masks) through the SAME layer stack as one stacked row batch: GEMMs, LayerNorms and their
+        backward kernels are launched once for all groups, attention once per group.  Numerically
+        identical to calling forward() per group (every other op is row-wise)."""
+        cd = HF.compute_dtype()
+        xs = [HF.cast(h, cd) for h in hidden_list]
+        segs = tuple((x.shape[0], x.shape[1]) for x in xs)
+        masks = tuple(HF.as_mask_add(m, s[0], s[1]) for m, s in zip(mask_list, segs))
+        D = xs[0].shape[-1]
+        x = torch.cat([t.reshape(-1, D) for t in xs], 0)
+        for layer in self.layer:
+            x = layer.forward_rows(x, segs, masks)
+        outs, r0 = [], 0
+        for (S, Lq) in segs:
+            outs.append(x[r0:r0 + S * Lq].view(S, Lq, D))
+            r0 += S * Lq
+        return outs
 
 
 class BertLMPredictionHead(nn.Module):

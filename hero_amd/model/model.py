@@ -153,8 +153,12 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         out = HF.CsrGatherSumFn.apply(frame_sequence_output, offs, ent, inv, B * NF)
         return out.view(B, NF, D)
 
-    def forward_repr(self, batch, encode_clip=True):
-        f_seq = self.f_encoder(batch, "repr")[0]                         # (total_subs, L_f, D)
+    def forward_repr(self, batch, encode_clip=True, f_seq=None):
+        """f_seq: optionally the cross-modal encoder output computed by the caller (see
+        HeroForPretraining.forward, which runs subtitle rows and query rows through the layer stack
+        in one pass)."""
+        if f_seq is None:
+            f_seq = self.f_encoder(batch, "repr")[0]                     # (total_subs, L_f, D)
         c_v_feats, c_attn_masks = batch["c_v_feats"], batch["c_attn_masks"]
         shape = list(c_v_feats.shape[:2]) + [f_seq.shape[-1]]
         matched = self.collect_frame_outputs(shape, f_seq, batch["num_subs"],

@@ -33,6 +33,7 @@ class HeroForPretraining(HeroModel):
         self.use_all_neg = use_all_neg
         self.drop_svmr_prob = drop_svmr_prob
         self.gather_gpus = True
+        self.fuse_query_pass = True   # subtitle rows and query rows share the cross-modal layer launches
         self.video_query_linear = nn.Linear(config.q_config.hidden_size, config.c_config.hidden_size)
         conv = dict(in_channels=1, out_channels=1, kernel_size=conv_kernel_size, stride=conv_stride,
                     padding=conv_kernel_size // 2, bias=False)
@@ -49,10 +50,22 @@ class HeroForPretraining(HeroModel):
                 return self.v_encoder(batch, task, compute_loss)
             raise ValueError(f"Unrecognized task {task}")
 
-        frame_embeddings = self.v_encoder(batch, "repr")
-        modularized_query = self.encode_txt_inputs(
-            batch["query_input_ids"], batch["query_pos_ids"], batch["query_attn_masks"],
-            attn_layer=self.q_feat_attn)
+        if self.fuse_query_pass:
+            # same math as the two reference calls (model/pretrain.py:65-70), one pass over the 6 layers
+            fe = self.v_encoder.f_encoder
+            emb_v = fe._compute_img_txt_embeddings(
+                batch["f_sub_input_ids"], batch["f_sub_pos_ids"], batch["f_v_feats"], batch["f_v_pos_ids"],
+                batch["f_gather_index"], img_masks=batch["f_v_masks"])
+            emb_q = fe._compute_txt_embeddings(batch["query_input_ids"], batch["query_pos_ids"])
+            seq_v, seq_q = fe.encoder.forward_multi([emb_v, emb_q],
+                                                    [batch["f_attn_masks"], batch["query_attn_masks"]])
+            frame_embeddings = self.v_encoder.forward_repr(batch, f_seq=seq_v)
+            modularized_query = self.q_feat_attn(seq_q, batch["query_attn_masks"])
+        else:
+            frame_embeddings = self.v_encoder(batch, "repr")
+            modularized_query = self.encode_txt_inputs(
+                batch["query_input_ids"], batch["query_pos_ids"], batch["query_attn_masks"],
+                attn_layer=self.q_feat_attn)
 
         q2video_scores = st_prob = ed_prob = None
         if self.lw_st_ed != 0:

@@ -481,7 +481,27 @@ struct GldsStageO {
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds(b + goff[i], (__attribute__((address_space(3))) void*)(lds + (lrow0 + i * 4) * 256), 16, 0, 0);
   }
+  // partial last tile: rows >= krem are fetched from the last valid row (then zeroed in LDS)
+  __device__ __forceinline__ void issue_tail(const bf16_t* __restrict__ b, char* lds, int krem, int ld) const {
+    const int rsub = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lrow0 + i * 4 + rsub;
+      const int back = row < krem ? 0 : row - (krem - 1);
+      __builtin_amdgcn_global_load_lds(b + goff[i] - back * ld, (__attribute__((address_space(3))) void*)(lds + (lrow0 + i * 4) * 256), 16, 0, 0);
+    }
+  }
 };
+
+// zero rows [krem, 64) of both operand images of a stage (all DMAs have landed, barrier passed)
+__device__ __forceinline__ void zero_tail_rows(char* stage, int krem) {
+  const int n = (64 - krem) * 16;
+  for (int idx = threadIdx.x; idx < n; idx += 256) {
+    const int off = (krem + (idx >> 4)) * 256 + (idx & 15) * 16;
+    *reinterpret_cast<uint4*>(stage + off) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(stage + 16384 + off) = make_uint4(0, 0, 0, 0);
+  }
+}
 
 // the 8 transpose reads of one k-step (2 A fragments + 2 B fragments, two halves each) + wait
 __device__ __forceinline__ void tr_frags(unsigned a0, unsigned a1, unsigned b0, unsigned b1, int ks, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) {
@@ -530,7 +550,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   sb.init(g.ldb, n0, g.N);
   const bf16_t* pa = static_cast<const bf16_t*>(g.A) + (size_t)tc.kbeg * g.lda + m0;
   const bf16_t* pb = static_cast<const bf16_t*>(g.B) + (size_t)tc.kbeg * g.ldb + n0;
-  const int nk = (tc.kend - tc.kbeg) / 64;
+  const int nk = (tc.kend - tc.kbeg + 63) / 64;
+  const int krem = (tc.kend - tc.kbeg) - (nk - 1) * 64;     // valid reduction rows in the last tile
+  const bool has_tail = krem != 64;
 
   // per-lane read offsets inside a tile image [64 k][256 B]
   const int p = lane & 15, gq = (lane >> 4) & 1, kg = lane >> 5;
@@ -543,19 +565,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
 
   if (nk > 0) {
-    sa.issue(pa, smem);
-    sb.issue(pb, smem + 16384);
+    if (nk == 1 && has_tail) {
+      sa.issue_tail(pa, smem, krem, g.lda);
+      sb.issue_tail(pb, smem + 16384, krem, g.ldb);
+    } else {
+      sa.issue(pa, smem);
+      sb.issue(pb, smem + 16384);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (nk == 1 && has_tail) {
+    zero_tail_rows(smem, krem);
+    __syncthreads();
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned cur = lds0 + (kt & 1) * 32768;
     char* nxt = smem + ((kt + 1) & 1) * 32768;
+    const bool tail_next = has_tail && kt + 2 == nk;
     if (kt + 1 < nk) {
       pa += (size_t)64 * g.lda;
       pb += (size_t)64 * g.ldb;
-      sa.issue(pa, nxt);
-      sb.issue(pb, nxt + 16384);
+      if (tail_next) {
+        sa.issue_tail(pa, nxt, krem, g.lda);
+        sb.issue_tail(pb, nxt + 16384, krem, g.ldb);
+      } else {
+        sa.issue(pa, nxt);
+        sb.issue(pb, nxt + 16384);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -569,6 +606,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tail_next) {                                  // uniform: only before the last, partial tile
+      zero_tail_rows(nxt, krem);
+      __syncthreads();
+    }
   }
   gemm_epilogue<bf16_t, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
@@ -775,8 +816,7 @@ static int launch_glds_tr(GemmArgs g, hipStream_t s) {
 
 template <typename T, int AL, int BL>
 static int launch_cfg(const GemmArgs& g, int cfg, hipStream_t s) {
-  if (AL == HERO_LAYOUT_O && BL == HERO_LAYOUT_O && sizeof(T) == 2 && g_use_glds && g.K > 0 && g.K % 64 == 0 &&
-      g.k_per_split % 64 == 0)
+  if (AL == HERO_LAYOUT_O && BL == HERO_LAYOUT_O && sizeof(T) == 2 && g_use_glds && g.K > 0 && g.k_per_split % 64 == 0)
     return launch_glds_tr(g, s);
   if (AL == HERO_LAYOUT_K && BL == HERO_LAYOUT_K && g_use_glds && g.K > 0 && g.K % Tr<T>::BK == 0 &&
       g.k_per_split % Tr<T>::BK == 0) {

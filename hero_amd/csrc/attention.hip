@@ -277,6 +277,215 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
   }
 }
 
+// =============================================================================================
+// Short sequences (L <= 64: every HERO training shape).  Q, K, V (and dO) of one (sequence, head)
+// are staged in LDS as fp32 with 16-byte aligned, conflict-free strides, so the inner loops are
+// ds_read_b128 + v_fma only (no bf16 unpacking); all keys fit one pass (64/LPK >= L), softmax runs
+// in registers with DPP reductions; the dK/dV phase walks 4 keys at a time (one broadcast b128 of
+// dS / P per query row feeds 8 FMAs).
+// =============================================================================================
+constexpr int KS = 68;   // fp32 row stride of matrices that are read row-per-lane with ds_read_b128
+
+template <typename T>
+__device__ __forceinline__ void stage_f32(const T* __restrict__ src, int ld, int L, float* dst, int stride) {
+  for (int q = threadIdx.x; q < L * 16; q += blockDim.x) {
+    const int r = q >> 4, c = (q & 15) * 4;
+    *reinterpret_cast<float4*>(dst + r * stride + c) = V4<T>::ld(src + (size_t)r * ld + c);
+  }
+}
+
+template <int DPL>
+__device__ __forceinline__ void row_regs(const float* row, float (&v)[DPL]) {
+#pragma unroll
+  for (int t = 0; t < DPL; t += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(row + t);
+    v[t] = x.x; v[t + 1] = x.y; v[t + 2] = x.z; v[t + 3] = x.w;
+  }
+}
+template <int DPL>
+__device__ __forceinline__ float dot_regs(const float (&q)[DPL], const float* row) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < DPL; t += 4) {
+    const float4 k = *reinterpret_cast<const float4*>(row + t);
+    s0 = fmaf(q[t], k.x, s0); s1 = fmaf(q[t + 1], k.y, s1);
+    s0 = fmaf(q[t + 2], k.z, s0); s1 = fmaf(q[t + 3], k.w, s1);
+  }
+  return s0 + s1;
+}
+
+template <typename T, int LPK>
+__global__ __launch_bounds__(256) void attn_fwd_small_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DPL = DH / LPK;
+  const int L = a.L, H = a.H, D = H * DH;
+  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Lp = (L + 3) & ~3;
+  float* Qs = reinterpret_cast<float*>(smem);
+  float* Ks = Qs + L * DH;
+  float* Vs = Ks + L * KS;
+  float* Ms = Vs + L * DH;
+  float* Ps = Ms + Lp + wave * Lp;
+
+  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D + h * DH;
+  stage_f32<T>(qkv, 3 * D, L, Qs, DH);
+  stage_f32<T>(qkv + D, 3 * D, L, Ks, KS);
+  stage_f32<T>(qkv + 2 * D, 3 * D, L, Vs, DH);
+  for (int j = threadIdx.x; j < L; j += 256) Ms[j] = a.mask ? a.mask[(size_t)s * L + j] : 0.f;
+  __syncthreads();
+
+  DropCtx drop(a.dropout);
+  const int g = lane / LPK, p = lane % LPK;
+  const bool valid = g < L;
+  T* ctx = static_cast<T*>(a.ctx) + (size_t)s * L * D + h * DH;
+  float* probs = a.probs ? a.probs + ((size_t)(s * H + h) * L) * L : nullptr;
+  const float mj = valid ? Ms[g] : 0.f;
+  const float* krow = Ks + (valid ? g : 0) * KS + p * DPL;
+
+  for (int i = wave; i < L; i += 4) {
+    float q[DPL];
+    row_regs<DPL>(Qs + i * DH + p * DPL, q);
+    float sc = group_sum<LPK>(dot_regs<DPL>(q, krow));
+    sc = valid ? sc * a.scale + mj : -3.0e38f;
+    const float mx = wave_max(sc);
+    const float e = valid ? __expf(sc - mx) : 0.f;
+    const float sum = wave_sum(p == 0 ? e : 0.f);
+    float pr = e * (1.f / sum);
+    if (valid && p == 0) {
+      if (probs) probs[(size_t)i * L + g] = pr;
+      if (drop.on()) pr *= drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + g);
+      Ps[g] = pr;
+    }
+    wave_lds_sync();
+    float acc0 = 0.f, acc1 = 0.f;
+    int j = 0;
+    for (; j + 4 <= L; j += 4) {
+      const float4 pj = *reinterpret_cast<const float4*>(Ps + j);
+      acc0 = fmaf(pj.x, Vs[(j + 0) * DH + lane], acc0);
+      acc1 = fmaf(pj.y, Vs[(j + 1) * DH + lane], acc1);
+      acc0 = fmaf(pj.z, Vs[(j + 2) * DH + lane], acc0);
+      acc1 = fmaf(pj.w, Vs[(j + 3) * DH + lane], acc1);
+    }
+    for (; j < L; ++j) acc0 = fmaf(Ps[j], Vs[j * DH + lane], acc0);
+    st1<T>(ctx + (size_t)i * D + lane, acc0 + acc1);
+    wave_lds_sync();
+  }
+}
+
+template <typename T, int LPK>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DPL = DH / LPK;
+  const int L = a.L, H = a.H, D = H * DH;
+  const int s = blockIdx.x / H, h = blockIdx.x % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Lp = (L + 3) & ~3;
+  float* Qs = reinterpret_cast<float*>(smem);   // [L][64]
+  float* Os = Qs + L * DH;                       // [L][64]  dO
+  float* Ks = Os + L * DH;                       // [L][68]
+  float* Vs = Ks + L * KS;                       // [L][68]
+  float* dS = Vs + L * KS;                       // [L][Lp]  (scaled)
+  float* Pd = dS + L * Lp;                       // [L][Lp]  P on entry, dropped P afterwards
+
+  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D + h * DH;
+  const T* dctx = static_cast<const T*>(a.dctx) + (size_t)s * L * D + h * DH;
+  stage_f32<T>(qkv, 3 * D, L, Qs, DH);
+  stage_f32<T>(qkv + D, 3 * D, L, Ks, KS);
+  stage_f32<T>(qkv + 2 * D, 3 * D, L, Vs, KS);
+  stage_f32<T>(dctx, D, L, Os, DH);
+  {
+    const float* src = a.probs + ((size_t)(s * H + h) * L) * L;
+    for (int q = threadIdx.x; q < L * L; q += 256) {
+      const int i = q / L, j = q - i * L;
+      Pd[i * Lp + j] = src[q];
+    }
+    for (int q = threadIdx.x; q < L * (Lp - L); q += 256) {   // zero the row padding read by the quad phase
+      const int i = q / (Lp - L), j = L + q % (Lp - L);
+      Pd[i * Lp + j] = 0.f;
+      dS[i * Lp + j] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  DropCtx drop(a.dropout);
+  const int g = lane / LPK, p = lane % LPK;
+  const bool valid = g < L;
+  T* dqkv = static_cast<T*>(a.dqkv) + (size_t)s * L * 3 * D + h * DH;
+  const float* vrow = Vs + (valid ? g : 0) * KS + p * DPL;
+
+  // ---- phase A: one wave per query row -> dS row, dropped-P row (LDS), dQ row (HBM)
+  for (int i = wave; i < L; i += 4) {
+    float ov[DPL];
+    row_regs<DPL>(Os + i * DH + p * DPL, ov);
+    float dp = group_sum<LPK>(dot_regs<DPL>(ov, vrow));
+    float* dSr = dS + i * Lp;
+    float* Pdr = Pd + i * Lp;
+    float pr = 0.f;
+    if (valid) {
+      pr = Pdr[g];
+      if (drop.on()) {
+        const float m = drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + g);
+        dp *= m;
+        if (p == 0) Pdr[g] = pr * m;
+      }
+    }
+    const float delta = wave_sum((valid && p == 0) ? dp * pr : 0.f);
+    if (valid && p == 0) dSr[g] = pr * (dp - delta) * a.scale;
+    wave_lds_sync();
+    float acc0 = 0.f, acc1 = 0.f;
+    int j = 0;
+    for (; j + 4 <= L; j += 4) {
+      const float4 d4 = *reinterpret_cast<const float4*>(dSr + j);
+      acc0 = fmaf(d4.x, Ks[(j + 0) * KS + lane], acc0);
+      acc1 = fmaf(d4.y, Ks[(j + 1) * KS + lane], acc1);
+      acc0 = fmaf(d4.z, Ks[(j + 2) * KS + lane], acc0);
+      acc1 = fmaf(d4.w, Ks[(j + 3) * KS + lane], acc1);
+    }
+    for (; j < L; ++j) acc0 = fmaf(dSr[j], Ks[j * KS + lane], acc0);
+    st1<T>(dqkv + (size_t)i * 3 * D + lane, acc0 + acc1);
+  }
+  __syncthreads();
+  // ---- phase B: a wave owns quads of keys; lane = feature column
+  const int nquads = Lp >> 2;
+  for (int jq = wave; jq < nquads; jq += 4) {
+    const int j0 = jq * 4;
+    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const float4 d4 = *reinterpret_cast<const float4*>(dS + i * Lp + j0);
+      const float4 p4 = *reinterpret_cast<const float4*>(Pd + i * Lp + j0);
+      const float qv = Qs[i * DH + lane], ovv = Os[i * DH + lane];
+      k0 = fmaf(d4.x, qv, k0); k1 = fmaf(d4.y, qv, k1); k2 = fmaf(d4.z, qv, k2); k3 = fmaf(d4.w, qv, k3);
+      v0 = fmaf(p4.x, ovv, v0); v1 = fmaf(p4.y, ovv, v1); v2 = fmaf(p4.z, ovv, v2); v3 = fmaf(p4.w, ovv, v3);
+    }
+    const float kk[4] = {k0, k1, k2, k3}, vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (j0 + t < L) {
+        st1<T>(dqkv + (size_t)(j0 + t) * 3 * D + D + lane, kk[t]);
+        st1<T>(dqkv + (size_t)(j0 + t) * 3 * D + 2 * D + lane, vv[t]);
+      }
+  }
+}
+
+static size_t small_fwd_lds(int L) { const int Lp = (L + 3) & ~3; return ((size_t)L * (DH + KS + DH) + 5 * Lp) * sizeof(float); }
+static size_t small_bwd_lds(int L) { const int Lp = (L + 3) & ~3; return ((size_t)L * (2 * DH + 2 * KS) + 2 * (size_t)L * Lp) * sizeof(float); }
+
+template <typename T, int LPK>
+static int launch_small(const HeroAttn& a, bool bwd, hipStream_t s) {
+  const size_t lds = bwd ? small_bwd_lds(a.L) : small_fwd_lds(a.L);
+  if (bwd) {
+    static size_t cap = 65536;
+    if (lds > cap) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cap = lds; }
+    hipLaunchKernelGGL((attn_bwd_small_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
+  } else {
+    static size_t cap = 65536;
+    if (lds > cap) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_small_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cap = lds; }
+    hipLaunchKernelGGL((attn_fwd_small_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
+  }
+  return check_launch(bwd ? "hero_attention_bwd(small)" : "hero_attention_fwd(small)");
+}
+
 constexpr size_t LDS_BUDGET = 150 * 1024;
 
 template <typename T> static size_t fwd_lds(int L) {
@@ -338,8 +547,9 @@ static int run(const HeroAttn& a, bool bwd, hipStream_t s) {
     set_error("hero_attention_%s: sequence length %d exceeds the LDS-resident limit %d for this dtype", bwd ? "bwd" : "fwd", a.L, lim);
     return HERO_ERR_UNSUPPORTED;
   }
-  if (a.L <= 16) return bwd ? bwd_by_len<T, 4>(a, s) : launch_fwd<T, 4>(a, s);
-  if (a.L <= 32) return bwd ? bwd_by_len<T, 2>(a, s) : launch_fwd<T, 2>(a, s);
+  if (a.L <= 16) return launch_small<T, 4>(a, bwd, s);
+  if (a.L <= 32) return launch_small<T, 2>(a, bwd, s);
+  if (a.L <= 64) return launch_small<T, 1>(a, bwd, s);
   return bwd ? bwd_by_len<T, 1>(a, s) : launch_fwd<T, 1>(a, s);
 }
 

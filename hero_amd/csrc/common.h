@@ -77,14 +77,36 @@ struct DropCtx {
   }
 };
 
+// Wave-wide reductions on the DPP network (no LDS round trips): row_shr 1/2/4/8 leave each 16-lane
+// row's total in its lane 15, row_bcast:15 / row_bcast:31 fold the four rows into lane 63, which
+// is read back through an SGPR.  The result is uniform across the wave.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float identity, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0x111, 0xf, 0xf>(0.f, v);
+  v += dpp_mov<0x112, 0xf, 0xf>(0.f, v);
+  v += dpp_mov<0x114, 0xf, 0xe>(0.f, v);
+  v += dpp_mov<0x118, 0xf, 0xc>(0.f, v);
+  v += dpp_mov<0x142, 0xa, 0xf>(0.f, v);
+  v += dpp_mov<0x143, 0xc, 0xf>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const float lo = -3.0e38f;
+  v = fmaxf(v, dpp_mov<0x111, 0xf, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<0x112, 0xf, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<0x114, 0xf, 0xe>(lo, v));
+  v = fmaxf(v, dpp_mov<0x118, 0xf, 0xc>(lo, v));
+  v = fmaxf(v, dpp_mov<0x142, 0xa, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<0x143, 0xc, 0xf>(lo, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// sum over the 2 or 4 adjacent lanes that share a key (quad_perm swaps)
+template <int LPK> __device__ __forceinline__ float group_sum(float v) {
+  if (LPK >= 2) v += dpp_mov<0xB1, 0xf, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
+  if (LPK >= 4) v += dpp_mov<0x4E, 0xf, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
   return v;
 }
 

@@ -225,29 +225,37 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(HeroLnBwd a, float* p
   }
 }
 
-// out_k[c] = beta*out_k[c] + sum_b partial[b][k][c] for k = 0..2 (outputs may be NULL)
+// out_k[c] = beta*out_k[c] + sum_b partial[b][k][c] for k = blockIdx.y (outputs may be NULL).
+// 16 float4 column groups x 16 partial-lanes per workgroup; fixed summation order.
 __global__ __launch_bounds__(256) void colred_final3_kernel(const float* partial, float* o0, float* o1, float* o2, int cols,
                                                             int nblocks, float beta) {
-  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  __shared__ float red[4][16];
-  const int wave = threadIdx.x >> 6;
-  float* outs[3] = {o0, o1, o2};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (!outs[k]) continue;                       // uniform
-    float s = 0.f;
-    if (c < cols)
-      for (int b = kl; b < nblocks; b += 16) s += partial[((size_t)b * 3 + k) * cols + c];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if ((threadIdx.x & 63) < 16) red[wave][cl] = s;
-    __syncthreads();
-    if (threadIdx.x < 16 && c < cols) {
-      s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-      outs[k][c] = (beta != 0.f ? beta * outs[k][c] : 0.f) + s;
+  const int k = blockIdx.y;
+  float* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
+  if (!out) return;
+  __shared__ float4 red[16][16];
+  const int cg = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = (blockIdx.x * 16 + cg) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols)
+    for (int b = kl; b < nblocks; b += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)b * 3 + k) * cols + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    __syncthreads();
+  red[kl][cg] = s;
+  __syncthreads();
+  if (kl == 0 && c < cols) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 v = red[j][cg];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (beta != 0.f) {
+      o = *reinterpret_cast<const float4*>(out + c);
+      o.x *= beta; o.y *= beta; o.z *= beta; o.w *= beta;
+    }
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    *reinterpret_cast<float4*>(out + c) = o;
   }
 }
 
@@ -442,8 +450,8 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
 #undef CALLF
     int rc = check_launch("hero_layernorm_bwd(fused)");
     if (rc) return rc;
-    hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 15) / 16), dim3(256), 0, s, partial, a->dgamma, a->dbeta, a->dbias_in,
-                       a->cols, nblk, a->grad_beta);
+    hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 63) / 64, 3), dim3(256), 0, s, partial, a->dgamma, a->dbeta,
+                       a->dbias_in, a->cols, nblk, a->grad_beta);
     return check_launch("hero_layernorm_bwd(final3)");
   }
   HERO_REQUIRE(!a->dbias_in, "hero_layernorm_bwd: dbias_in needs cols <= 1024");

@@ -360,9 +360,9 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
     return dx, (dxd if dxd is not None else dx), dg, db
 
 
-def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True):
+def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None):
     D = H * 64
-    ctx = torch.empty((S * Lq, D), dtype=qkv.dtype, device=qkv.device)
+    ctx = out if out is not None else torch.empty((S * Lq, D), dtype=qkv.dtype, device=qkv.device)
     probs = torch.empty((S, H, Lq, Lq), dtype=torch.float32, device=qkv.device) if want_probs else None
     a = L.Attn(L.ptr(qkv), L.ptr(mask_add), L.ptr(ctx), L.ptr(probs), None, None, S, Lq, H,
                1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop))
@@ -370,8 +370,8 @@ def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True):
     return ctx, probs
 
 
-def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None):
-    dqkv = torch.empty_like(qkv)
+def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None, out=None):
+    dqkv = out if out is not None else torch.empty_like(qkv)
     a = L.Attn(L.ptr(qkv), None, None, L.ptr(probs), L.ptr(dctx), L.ptr(dqkv), S, Lq, H,
                1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop))
     L.check(L.lib().hero_attention_bwd(C.byref(a), L.stream()))
@@ -685,14 +685,13 @@ class AttnBlockFn(torch.autograd.Function):
         bqkv = packed((bq, bk, bv), torch.float32)
         Wo = packed((wo,), x2.dtype)
         qkv = k_linear(x2, Wqkv, bqkv)
-        ctxs, probs = [], []
+        ctxt = torch.empty((x2.shape[0], D), dtype=x2.dtype, device=x2.device)
+        probs = []
         r0 = 0
-        for (S, Lq), m, dr in zip(segs, masks, drops_attn):
-            c, p = k_attn_fwd(qkv[r0:r0 + S * Lq], m, S, Lq, H, drop=dr)
-            ctxs.append(c)
+        for (S, Lq), m, dr in zip(segs, masks, drops_attn):      # each group writes its row slice
+            _, p = k_attn_fwd(qkv[r0:r0 + S * Lq], m, S, Lq, H, drop=dr, out=ctxt[r0:r0 + S * Lq])
             probs.append(p)
             r0 += S * Lq
-        ctxt = ctxs[0] if len(ctxs) == 1 else torch.cat(ctxs, 0)
         y1 = k_linear(ctxt, Wo, bo.detach(), residual=x2, drop=drop_hid)
         a, mean, rstd, _ = k_ln_fwd(y1, g1.detach(), b1.detach(), eps, y1.dtype, x2.shape[0], D)
         ctx.meta = (segs, H, D, drops_attn, drop_hid, x.shape)
@@ -718,12 +717,12 @@ class AttnBlockFn(torch.autograd.Function):
             SINK.done(bo)
         acc_linear_grads(dy1d, ctxt, wo, None if fuse_b else bo)
         dctx = k_dgrad_t(dy1d, Wo_t)
-        dqs = []
+        dqkv = torch.empty_like(qkv)
         r0 = 0
         for (S, Lq), p, dr in zip(segs, probs, drops_attn):
-            dqs.append(k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr))
+            k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr,
+                       out=dqkv[r0:r0 + S * Lq])
             r0 += S * Lq
-        dqkv = dqs[0] if len(dqs) == 1 else torch.cat(dqs, 0)
         _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
         dx = k_dgrad_t(dqkv, Wqkv_t, residual=dy1).view(xshape)    # + residual-path gradient, fused
         return (dx,) + (None,) * 16

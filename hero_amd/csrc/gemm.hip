@@ -244,13 +244,18 @@ struct GemmArgs {
 // ---------------------------------------------------------------------------------------------
 // epilogue shared by both staging flavours
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename CF>
+// EK selects the epilogue features at COMPILE time for the hot-path combinations (the generic
+// runtime-flag version costs thousands of instructions per thread); EK_GENERIC keeps every flag.
+enum { EK_GENERIC = 0x100, EK_BIAS = 1, EK_GELU = 2, EK_RES = 4, EK_DROP = 8, EK_GELU_BWD = 16 };
+
+template <typename T, typename CF, int EK>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)[CF::TM][CF::TN], char* smem, int m0, int n0,
                                               int arow0, int brow0, int lane) {
   constexpr int BM = CF::BM, BN = CF::BN, NT = CF::NT, TM = CF::TM, TN = CF::TN;
+  constexpr bool GEN = (EK & EK_GENERIC) != 0;
   const HeroGemmEpilogue& e = g.epi;
   // ---- split-K: fp32 atomics straight from the accumulator layout
-  if (e.split_k > 1) {
+  if (GEN && e.split_k > 1) {
     float* C = static_cast<float*>(g.C);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -269,8 +274,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   // ---- accumulators -> LDS (128 rows x BN fp32 per pass) -> vectorised epilogue
   float* lc = reinterpret_cast<float*>(smem);
   DropCtx drop(e.dropout);
-  const T* R = static_cast<const T*>(e.residual);
+  const T* R = (GEN || (EK & EK_RES)) ? static_cast<const T*>(e.residual) : nullptr;
   T* X = static_cast<T*>(e.aux);
+  const int act = GEN ? e.act : ((EK & EK_GELU) ? HERO_ACT_GELU : ((EK & EK_GELU_BWD) ? HERO_ACT_GELU_BWD : HERO_ACT_NONE));
+  const bool use_bias = GEN ? (e.bias != nullptr) : ((EK & EK_BIAS) != 0);
+  const bool use_drop = (GEN || (EK & EK_DROP)) && drop.on();
+  const bool out_f32 = GEN && e.out_f32;
   constexpr int PASSES = BM / 128;
   constexpr int C4 = BN / 4;                        // float4 per row
   constexpr int ITERS = 128 * C4 / NT;
@@ -298,9 +307,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
     const bool col_ok = gn < g.N;
     const int gnc = min(gn, g.N - 4);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e.bias) bias4 = *reinterpret_cast<const float4*>(e.bias + gnc);
-    const bool ld_aux = e.act == HERO_ACT_GELU_BWD || e.act == HERO_ACT_RELU_BWD;
-    const bool ld_c = e.out_f32 && e.beta != 0.f;
+    if (use_bias) bias4 = *reinterpret_cast<const float4*>(e.bias + gnc);
+    const bool ld_aux = act == HERO_ACT_GELU_BWD || act == HERO_ACT_RELU_BWD;
+    const bool ld_c = out_f32 && e.beta != 0.f;
     constexpr int RSTEP = NT / C4;                 // rows covered per iteration
     constexpr int UN = 4;
 #pragma unroll 1
@@ -323,24 +332,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         const int row = threadIdx.x / C4 + (it0 + u) * RSTEP;
         float4 v = *reinterpret_cast<const float4*>(lc + row * BN + c4);
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-        if (e.act == HERO_ACT_GELU) {
+        if (act == HERO_ACT_GELU) {
           if (ok[u]) V4<T>::st(X + off[u], v);
           v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-        } else if (e.act == HERO_ACT_RELU) {
+        } else if (GEN && act == HERO_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           if (X && ok[u]) V4<T>::st(X + off[u], v);
-        } else if (e.act == HERO_ACT_GELU_BWD) {
+        } else if (act == HERO_ACT_GELU_BWD) {
           v.x *= gelu_erf_grad(uu[u].x); v.y *= gelu_erf_grad(uu[u].y); v.z *= gelu_erf_grad(uu[u].z); v.w *= gelu_erf_grad(uu[u].w);
-        } else if (e.act == HERO_ACT_RELU_BWD) {
+        } else if (GEN && act == HERO_ACT_RELU_BWD) {
           v.x = uu[u].x > 0.f ? v.x : 0.f; v.y = uu[u].y > 0.f ? v.y : 0.f; v.z = uu[u].z > 0.f ? v.z : 0.f; v.w = uu[u].w > 0.f ? v.w : 0.f;
         }
-        if (drop.on()) {
+        if (use_drop) {
           const int gm = m0 + pass * 128 + row;
           const float4 mk = drop.mask4(((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2);
           v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
         }
         if (R) { v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w; }
-        if (e.out_f32) {
+        if (out_f32) {
           if (ld_c) { v.x += e.beta * cc[u].x; v.y += e.beta * cc[u].y; v.z += e.beta * cc[u].z; v.w += e.beta * cc[u].w; }
           if (ok[u]) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + off[u]) = v;
         } else {
@@ -406,7 +415,7 @@ struct GldsStage {
   }
 };
 
-template <typename T, typename CF>
+template <typename T, typename CF, int EK>
 __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_glds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = Tr<T>::BK, BM = CF::BM, BN = CF::BN, NT = CF::NT, TM = CF::TM, TN = CF::TN;
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                 // next tile landed, everyone done with cur
   }
-  gemm_epilogue<T, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
+  gemm_epilogue<T, CF, EK>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       __syncthreads();
     }
   }
-  gemm_epilogue<bf16_t, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
+  gemm_epilogue<bf16_t, CF, EK_GENERIC>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
 
 template <typename T, int ALAY, int BLAY, typename CF>
@@ -676,7 +685,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) 
     __syncthreads();
   }
 
-  gemm_epilogue<T, CF>(g, acc, smem, m0, n0, arow0, brow0, lane);
+  gemm_epilogue<T, CF, EK_GENERIC>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
 
 // out <- beta * out over an [M, N] fp32 matrix (pre-pass of the split-K atomics path)
@@ -752,11 +761,26 @@ static int pick_cfg(int M, int N, int split, bool k_contig) {
 
 static int g_use_glds = 1;   // tuning hook
 
-template <typename T, typename CF>
-static int launch_glds(GemmArgs g, hipStream_t s) {
+// explicit instantiations (hipcc does not emit the host stubs for kernels that are only reached
+// through two levels of host-side templates)
+#define HERO_GLDS_INST(T, CF)                                                       \
+  template __global__ void gemm_glds_kernel<T, CF, EK_GENERIC>(GemmArgs);           \
+  template __global__ void gemm_glds_kernel<T, CF, 0>(GemmArgs);                    \
+  template __global__ void gemm_glds_kernel<T, CF, EK_BIAS>(GemmArgs);              \
+  template __global__ void gemm_glds_kernel<T, CF, EK_BIAS | EK_RES | EK_DROP>(GemmArgs); \
+  template __global__ void gemm_glds_kernel<T, CF, EK_BIAS | EK_GELU>(GemmArgs);    \
+  template __global__ void gemm_glds_kernel<T, CF, EK_RES>(GemmArgs);               \
+  template __global__ void gemm_glds_kernel<T, CF, EK_GELU_BWD>(GemmArgs);
+HERO_GLDS_INST(bf16_t, Cfg128)
+HERO_GLDS_INST(bf16_t, Cfg256)
+template __global__ void gemm_glds_kernel<float, Cfg128, EK_GENERIC>(GemmArgs);
+template __global__ void gemm_glds_kernel<float, Cfg256, EK_GENERIC>(GemmArgs);
+
+template <typename T, typename CF, int EK>
+static int launch_glds_ek(GemmArgs g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, CF, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
     attr_set = true;
   }
   g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
@@ -773,7 +797,7 @@ static int launch_glds(GemmArgs g, hipStream_t s) {
       ps = nullptr;
     }
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<T, CF>), dim3(grid), dim3(CF::NT), CF::LDS, s, g);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CF, EK>), dim3(grid), dim3(CF::NT), CF::LDS, s, g);
   if (ps) {
     (void)hipEventRecord(e1, s);
     ps->ev.push_back(e0);
@@ -781,6 +805,23 @@ static int launch_glds(GemmArgs g, hipStream_t s) {
     ps->flops.push_back(2.0 * (double)g.M * (double)g.N * (double)g.K);
   }
   return check_launch("hero_gemm(glds)");
+}
+
+// epilogue specialisation: the hot-path combinations of the bf16 training step get their own
+// instantiation, everything else (and all of f32) the generic one
+template <typename T, typename CF>
+static int launch_glds(const GemmArgs& g, hipStream_t s) {
+  const HeroGemmEpilogue& e = g.epi;
+  if constexpr (sizeof(T) == 2) if (!e.out_f32 && e.split_k <= 1) {
+    const bool b = e.bias != nullptr, r = e.residual != nullptr, d = e.dropout.threshold16 != 0;
+    if (e.act == HERO_ACT_NONE && b && !r && !d) return launch_glds_ek<T, CF, EK_BIAS>(g, s);
+    if (e.act == HERO_ACT_NONE && b && r) return launch_glds_ek<T, CF, EK_BIAS | EK_RES | EK_DROP>(g, s);
+    if (e.act == HERO_ACT_GELU && b && !r && !d) return launch_glds_ek<T, CF, EK_BIAS | EK_GELU>(g, s);
+    if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch_glds_ek<T, CF, 0>(g, s);
+    if (e.act == HERO_ACT_NONE && !b && r && !d) return launch_glds_ek<T, CF, EK_RES>(g, s);
+    if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch_glds_ek<T, CF, EK_GELU_BWD>(g, s);
+  }
+  return launch_glds_ek<T, CF, EK_GENERIC>(g, s);
 }
 
 static int launch_glds_tr(GemmArgs g, hipStream_t s) {

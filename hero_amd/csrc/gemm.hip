@@ -42,7 +42,8 @@ template <int WM_, int WN_, int TM_, int TN_> struct Cfg {
   static constexpr int NT = 64 * WM * WN;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static constexpr int EPI_BYTES = 128 * BN * 4;                      // 128 output rows of fp32
+  static constexpr int EPI_ROWS = BM < 128 ? BM : 128;                // output rows per epilogue pass
+  static constexpr int EPI_BYTES = EPI_ROWS * BN * 4;                 // one pass of fp32
   static constexpr int LDS = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
 };
 
@@ -280,14 +281,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   const bool use_bias = GEN ? (e.bias != nullptr) : ((EK & EK_BIAS) != 0);
   const bool use_drop = (GEN || (EK & EK_DROP)) && drop.on();
   const bool out_f32 = GEN && e.out_f32;
-  constexpr int PASSES = BM / 128;
+  constexpr int PR = CF::EPI_ROWS;                  // rows per pass
+  constexpr int PASSES = BM / PR;
   constexpr int C4 = BN / 4;                        // float4 per row
-  constexpr int ITERS = 128 * C4 / NT;
+  constexpr int ITERS = PR * C4 / NT;
 #pragma unroll 1
   for (int pass = 0; pass < PASSES; ++pass) {
     if (pass) __syncthreads();
-    if (arow0 / 128 == pass) {
-      const int rbase = arow0 - pass * 128;
+    if (arow0 / PR == pass) {
+      const int rbase = arow0 - pass * PR;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -320,7 +322,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
 #pragma unroll
       for (int u = 0; u < UN; ++u) {               // all global loads of the group first (batched)
         const int row = threadIdx.x / C4 + (it0 + u) * RSTEP;
-        const int gm = m0 + pass * 128 + row;
+        const int gm = m0 + pass * PR + row;
         ok[u] = col_ok && gm < g.M;
         off[u] = (size_t)min(gm, g.M - 1) * g.ldc + gnc;
         if (R) rr[u] = V4<T>::ld(R + off[u]);
@@ -334,17 +336,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
         if (act == HERO_ACT_GELU) {
           if (ok[u]) V4<T>::st(X + off[u], v);
-          v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+          v.x = gelu_fwd<T>(v.x); v.y = gelu_fwd<T>(v.y); v.z = gelu_fwd<T>(v.z); v.w = gelu_fwd<T>(v.w);
         } else if (GEN && act == HERO_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           if (X && ok[u]) V4<T>::st(X + off[u], v);
         } else if (act == HERO_ACT_GELU_BWD) {
-          v.x *= gelu_erf_grad(uu[u].x); v.y *= gelu_erf_grad(uu[u].y); v.z *= gelu_erf_grad(uu[u].z); v.w *= gelu_erf_grad(uu[u].w);
+          v.x *= gelu_grad<T>(uu[u].x); v.y *= gelu_grad<T>(uu[u].y); v.z *= gelu_grad<T>(uu[u].z); v.w *= gelu_grad<T>(uu[u].w);
         } else if (GEN && act == HERO_ACT_RELU_BWD) {
           v.x = uu[u].x > 0.f ? v.x : 0.f; v.y = uu[u].y > 0.f ? v.y : 0.f; v.z = uu[u].z > 0.f ? v.z : 0.f; v.w = uu[u].w > 0.f ? v.w : 0.f;
         }
         if (use_drop) {
-          const int gm = m0 + pass * 128 + row;
+          const int gm = m0 + pass * PR + row;
           const float4 mk = drop.mask4(((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2);
           v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
         }
@@ -715,6 +717,7 @@ static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2); -1 = he
 
 typedef Cfg<2, 2, 2, 2> Cfg128;
 typedef Cfg<2, 4, 4, 2> Cfg256;
+typedef Cfg<2, 2, 1, 1> Cfg64;     // 64x64 tiles for problems that leave most CUs idle at 128x128
 
 template <typename T, int AL, int BL, typename CF>
 static int launch(GemmArgs g, hipStream_t s) {
@@ -753,6 +756,7 @@ static int launch(GemmArgs g, hipStream_t s) {
 static int pick_cfg(int M, int N, int split, bool k_contig) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (!k_contig || split != 1) return 0;
+  if ((long long)((M + 127) / 128) * ((N + 127) / 128) <= 192) return 3;   // under one 128^2 tile per CU
   // one 256x256 workgroup per CU: only worth it when the tiles fill whole rounds of the 256 CUs
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const long long rounds = (tiles + 255) / 256;
@@ -773,6 +777,8 @@ static int g_use_glds = 1;   // tuning hook
   template __global__ void gemm_glds_kernel<T, CF, EK_GELU_BWD>(GemmArgs);
 HERO_GLDS_INST(bf16_t, Cfg128)
 HERO_GLDS_INST(bf16_t, Cfg256)
+HERO_GLDS_INST(bf16_t, Cfg64)
+template __global__ void gemm_glds_kernel<float, Cfg64, EK_GENERIC>(GemmArgs);
 template __global__ void gemm_glds_kernel<float, Cfg128, EK_GENERIC>(GemmArgs);
 template __global__ void gemm_glds_kernel<float, Cfg256, EK_GENERIC>(GemmArgs);
 
@@ -862,6 +868,7 @@ static int launch_cfg(const GemmArgs& g, int cfg, hipStream_t s) {
   if (AL == HERO_LAYOUT_K && BL == HERO_LAYOUT_K && g_use_glds && g.K > 0 && g.K % Tr<T>::BK == 0 &&
       g.k_per_split % Tr<T>::BK == 0) {
     if (cfg == 2) return launch_glds<T, Cfg256>(g, s);
+    if (cfg == 3) return launch_glds<T, Cfg64>(g, s);
     return launch_glds<T, Cfg128>(g, s);
   }
   if (cfg == 2) return launch<T, AL, BL, Cfg256>(g, s);
@@ -934,7 +941,7 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, cfg, s) : dispatch<float>(g, a_layout, b_layout, cfg, s);
 }
 
-// Tuning hook: force a tile geometry (0: 128x128, 1: 128x256, 2: 256x256, -1: heuristic).
+// Tuning hook: force a tile geometry (0: 128x128, 2: 256x256, 3: 64x64 [direct-to-LDS path only], -1: heuristic).
 extern "C" int hero_gemm_force_config(int cfg) {
   g_force_cfg = cfg >= 0 ? (cfg & 3) : -1;
   g_use_glds = cfg >= 0 ? !(cfg & 4) : 1;      // bit 2 set: register staging even for K,K operands

@@ -76,6 +76,36 @@ def test_gemm_dgrad_wgrad(HF, Lb, dtype, M, N, K):
     close(HF.k_colsum(dy), dy.float().sum(0), torch.float32, scale=math.sqrt(M) * (1 if dtype == torch.float32 else 1))
 
 
+@pytest.mark.parametrize("cfg", [0, 2, 3, 4])
+def test_gemm_forced_geometries(HF, Lb, cfg):
+    """Every tile geometry of the K-contiguous path (128x128, 256x256, 64x64) and the register-staged
+    loop (bit 2) give the same result on a ragged shape, with the fused epilogues."""
+    dtype = torch.bfloat16
+    M, N, K = 700, 776, 768
+    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
+    res = rnd(M, N, dtype=dtype, seed=4)
+    ref = x.float() @ w.float().t() + b
+    Lb.lib().hero_gemm_force_config(cfg)
+    try:
+        y0 = HF.k_linear(x, w, b)
+        aux = torch.empty_like(y0)
+        y1 = HF.k_linear(x, w, b, act=Lb.ACT_GELU, aux=aux)
+        y2 = HF.k_linear(x, w, b, residual=res)
+        dy = rnd(M, N, dtype=dtype, seed=5)
+        wt = w.t().contiguous()                      # [K, N]: dgrad through the transposed copy
+        dx = HF.k_dgrad_t(dy, wt, act=Lb.ACT_GELU_BWD, aux=x)
+    finally:
+        Lb.lib().hero_gemm_force_config(-1)
+    sc = math.sqrt(K) * 0.05
+    close(y0, ref, dtype, scale=sc)
+    close(aux, ref, dtype, scale=sc)
+    close(y1, torch.nn.functional.gelu(ref), dtype, scale=sc)
+    close(y2, ref + res.float(), dtype, scale=sc + 1)
+    xf = x.float()
+    gp = 0.5 * (1 + torch.erf(xf / math.sqrt(2))) + xf * torch.exp(-0.5 * xf * xf) / math.sqrt(2 * math.pi)
+    close(dx, (dy.float() @ w.float()) * gp, dtype, scale=math.sqrt(N) * 0.05 * 2)
+
+
 def test_gemm_transpose_detecting(HF, Lb):
     """A = I with an asymmetric B catches row/column swaps in the MFMA fragment maps."""
     for dtype in DT:

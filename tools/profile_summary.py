@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output into the small summaries committed under profiles/.
+
+  python tools/profile_summary.py stats <dir-with-*_kernel_stats.csv> <micro-steps-in-trace> <out.csv> ["header note"]
+  python tools/profile_summary.py pmc <fetch-dir> <write-dir> <out.json>
+
+`stats`: per-kernel calls / total ms / average us PER MICRO-STEP from `rocprofv3 --kernel-trace --stats`.
+`pmc`:  per-kernel average FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them; collected in two
+        separate --pmc passes because the TCC block cannot hold both) and the corrected HBM bytes per
+        launch: FETCH_SIZE x 2 (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md
+        "HBM") + WRITE_SIZE.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def _one(d, pat):
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    if not hits:
+        raise SystemExit("no %s under %s" % (pat, d))
+    return hits[0]
+
+
+def stats(d, steps, out, note=""):
+    rows = list(csv.DictReader(open(_one(d, "*kernel_stats.csv"))))
+    steps = float(steps)
+    total = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
+    with open(out, "w") as f:
+        if note:
+            f.write("# %s\n" % note)
+        f.write("# %g micro-steps in the trace; total kernel time %.2f ms/step\n" % (steps, total))
+        f.write("name,calls_per_step,total_ms_per_step,avg_us,pct\n")
+        for r in rows:
+            f.write('"%s",%.1f,%.3f,%.2f,%s\n' % (r["Name"], float(r["Calls"]) / steps,
+                                                   float(r["TotalDurationNs"]) / steps / 1e6,
+                                                   float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    print("kernel time %.2f ms/step -> %s" % (total, out))
+
+
+def _counter(d, name):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(_one(d, "*counter_collection.csv"))):
+        if r["Counter_Name"] == name:
+            a = acc[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return acc
+
+
+def pmc(fd, wd, out):
+    fe, wr = _counter(fd, "FETCH_SIZE"), _counter(wd, "WRITE_SIZE")
+    res = {}
+    for k, (n, tot) in fe.items():
+        if "hero::" not in k or k not in wr:
+            continue
+        f_kb = tot / n
+        w_kb = wr[k][1] / wr[k][0]
+        res[k] = {"launches": n, "FETCH_SIZE_KB_avg": f_kb, "WRITE_SIZE_KB_avg": w_kb,
+                  "hbm_bytes_per_launch_corrected": (2.0 * f_kb + w_kb) * 1024.0}
+    json.dump(res, open(out, "w"), indent=1)
+    print("%d kernels -> %s" % (len(res), out))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(*sys.argv[2:])
+    elif sys.argv[1] == "pmc":
+        pmc(*sys.argv[2:])
+    else:
+        raise SystemExit(__doc__)

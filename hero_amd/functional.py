@@ -12,6 +12,7 @@ Block structure (one autograd node each, residual fan-in fused into GEMM epilogu
 import ctypes as C
 import math
 
+import os
 import torch
 
 from . import _lib as L
@@ -247,10 +248,28 @@ def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None):
 
 
 def _split_for(n_out, n_in, rows, bk):
+    """Split of the reduction (the M rows) for dW = dY^T X.  The [n_out, n_in] output has few
+    128x128 tiles, so the row range is cut across workgroups and fp32 atomics merge the partial
+    sums.  The split minimises a cost model fitted on MI355X (tools/wgrad_sweep.py): a workgroup
+    runs at ~2.7 TFLOP/s alone on a CU and ~1.83 when two share it (512 resident slots on 256
+    CUs), and the atomic merge moves split x output bytes at ~2 TB/s."""
     tiles = ((n_out + 127) // 128) * ((n_in + 127) // 128)
-    split = max(1, min(8, -(-256 // tiles)))
     ktiles = max(1, -(-rows // bk))
-    return max(1, min(split, ktiles // 4))
+    flops = 2.0 * n_out * n_in * rows
+    out_bytes = 4.0 * n_out * n_in
+    best, best_t = 1, None
+    for s in range(1, 17):
+        if s > 1 and ktiles // s < 4:
+            break
+        blocks = tiles * s
+        rounds = -(-blocks // 512)
+        last = blocks - (rounds - 1) * 512
+        t = flops / blocks * ((rounds - 1) / 1.83e12 + (1 / 2.7e12 if last <= 256 else 1 / 1.83e12))
+        if s > 1:
+            t += out_bytes * s / 2.0e12
+        if best_t is None or t < best_t:
+            best, best_t = s, t
+    return best
 
 
 def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None):

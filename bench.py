@@ -37,7 +37,7 @@ HERO_BASE = {  # config/hero_finetune.json
 VFEAT = 4352
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
 SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (K-contiguous operands: forward x W^T and dgrad dY (W^T)^T)",
-              5: "gemm_kernel<bf16,K,O>", 7: "gemm_kernel<bf16,O,O> (wgrad dY^T X)", 6: "gemm_kernel<bf16,O,K>"}
+              5: "gemm_kernel<bf16,K,O>", 7: "gemm_glds_tr_kernel (bf16 wgrad dY^T X)", 6: "gemm_kernel<bf16,O,K>"}
 
 
 def algorithmic_flops_per_video(sh):
@@ -172,7 +172,7 @@ def main():
                 pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
                 pm = json.load(open(pj))
                 want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
-                        7: "gemm_kernel<unsigned short, 1, 1"}.get(slot)
+                        7: "gemm_glds_tr_kernel"}.get(slot)
                 hits = [v for k, v in pm.items() if want and want in k]
                 if hits:
                     tot = sum(h["launches"] for h in hits)

@@ -12,6 +12,7 @@
 //            V row read conflict-free).
 // The fp32 softmax output is written out for the backward pass (a few MB per layer at HERO's
 // lengths), the dropout mask is regenerated from the counter RNG.
+#include <stdlib.h>
 #include "common.h"
 
 namespace hero {
@@ -540,8 +541,16 @@ static int bwd_by_len(const HeroAttn& a, hipStream_t s) {
   if (a.L <= 128) return launch_bwd<T, LPK, 32>(a, s);
   return launch_bwd<T, LPK, 64>(a, s);
 }
+int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s);   // attention_mfma.hip (bf16, L <= 64)
+
+static bool use_mfma() {   // tuning hook: HERO_ATTN_MFMA=0 keeps the fp32-VALU kernels for bf16 too
+  static const bool on = [] { const char* e = getenv("HERO_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <typename T>
 static int run(const HeroAttn& a, bool bwd, hipStream_t s) {
+  if (sizeof(T) == 2 && a.L <= 64 && use_mfma()) return attn_mfma_run(a, bwd, s);
   const int lim = max_len<T>(bwd ? 1 : 0);
   if (a.L > lim) {
     set_error("hero_attention_%s: sequence length %d exceeds the LDS-resident limit %d for this dtype", bwd ? "bwd" : "fwd", a.L, lim);

@@ -1,0 +1,423 @@
+// Short-sequence (L <= 64) masked multi-head self-attention on the matrix cores, bf16, head size 64.
+//
+// One WAVE owns one (sequence, head).  All five products of attention are 32x32x16 bf16 MFMAs on
+// the head's (padded) 32- or 64-row tiles, everything between them stays in registers:
+//
+//   forward   S^T = K Q^T        A = K rows, B = Q rows: 16-byte fragment loads straight from HBM
+//             softmax over keys  in the accumulator layout of S^T: lane <-> query, 16 keys per
+//                                lane per tile (+ one cross-half exchange), no LDS
+//             ctx^T = V^T P^T    A = V^T by ds_read_b64_tr_b16 from the LDS-staged V tile,
+//                                B = P straight from the softmax registers (the key <-> k-slot
+//                                assignment is chosen so that each lane already holds its slots)
+//   backward  dP^T = V dO^T      same shape as S^T
+//             dS                 in registers (lane <-> query), delta_i by the same exchange
+//             dQ^T = K^T dS^T    as ctx^T
+//             dV^T = dO^T P, dK^T = Q^T dS   contraction over queries: P and dS go through LDS
+//                                once ([query][key] bf16) and come back as transposed fragments
+//
+// The fp32-VALU kernels this replaces (attention.hip, kept for the f32 parity mode and L > 64)
+// issue ~5000 wave instructions per head; this one ~400, which moves short-sequence attention
+// from VALU-issue-bound to memory/latency-bound.
+//
+// Reference semantics: model/layers.py:129-160 (scores / sqrt(64) + additive mask, softmax,
+// dropout on the probabilities, context).  Dropout indices are those of HeroAttn (hero_hip.h).
+#include "common.h"
+
+namespace hero {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+namespace {
+
+constexpr int RS = 72;   // LDS row stride (bf16 elements) of a [rows][64] head tile: 144 B, conflict-free b128 / tr reads
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// [L][64] bf16 head slice (row stride ld) -> wave-private LDS tile [32*NB][RS], rows >= L zeroed
+template <int NB>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int L, bf16_t* dst, int lane) {
+  uint4 v[4 * NB];
+  const int c = (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4 * NB; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    v[it] = *reinterpret_cast<const uint4*>(src + (size_t)min(r, L - 1) * ld + c);
+  }
+#pragma unroll
+  for (int it = 0; it < 4 * NB; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    uint4 t = v[it];
+    if (r >= L) t = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(dst + r * RS + c) = t;
+  }
+}
+
+// row fragment (MFMA A or B operand with the contraction along the row): 8 consecutive elements
+__device__ __forceinline__ bf16x8_t gfrag(const bf16_t* __restrict__ base, int ld, int row, int L, int ks, int half) {
+  return *reinterpret_cast<const bf16x8_t*>(base + (size_t)min(row, L - 1) * ld + 16 * ks + 8 * half);
+}
+__device__ __forceinline__ bf16x8_t lfrag(const bf16_t* tile, int row, int ks, int half) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * RS + 16 * ks + 8 * half);
+}
+
+// transposed fragment: the lane's 8 k-slots are rows (ra .. ra+3) and (rb .. rb+3) of an LDS tile,
+// its m/n index is column cb*32 + (lane & 31).  `stride_b` = row stride in bytes.
+__device__ __forceinline__ unsigned tr_addr(const void* tile, int stride_b, int row0, int cb, int lane) {
+  const int p = lane & 15, gq = (lane >> 4) & 1;
+  return (unsigned)(uintptr_t)tile + (row0 + (p >> 2)) * stride_b + (cb * 32 + gq * 16 + 4 * (p & 3)) * 2;
+}
+__device__ __forceinline__ bf16x8_t tr_frag(unsigned addr_a, unsigned addr_b) {
+  uint2 r0, r1;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %2\n\t"
+      "ds_read_b64_tr_b16 %1, %3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1)
+      : "v"(addr_a), "v"(addr_b)
+      : "memory");
+  const u32x4_t t = {r0.x, r0.y, r1.x, r1.y};
+  return __builtin_bit_cast(bf16x8_t, t);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const float* v) {
+  const u32x4_t t = {f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]), f2bf_pk(v[4], v[5]), f2bf_pk(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8_t, t);
+}
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// key (or, in the backward's LDS round trip, query) index of accumulator register r in a 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// 8-byte store of 4 consecutive head dims
+__device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, float d) {
+  uint2 u;
+  u.x = f2bf_pk(a, b);
+  u.y = f2bf_pk(c, d);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+// out^T[dt][nt] (head dim x lane-owned row) -> out[row][h*64 + d], rows < L
+template <int NB>
+__device__ __forceinline__ void store_headT(bf16_t* __restrict__ dst, int ld, int L, const f32x16_t (&acc)[2][NB], int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NB; ++nt) {
+    const int row = 32 * nt + l31;
+    if (row < L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          st_bf4(dst + (size_t)row * ld + 32 * dt + 8 * q + 4 * half, acc[dt][nt][4 * q], acc[dt][nt][4 * q + 1],
+                 acc[dt][nt][4 * q + 2], acc[dt][nt][4 * q + 3]);
+    }
+  }
+}
+
+template <int NB, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int pair = blockIdx.x * WPB + wave;
+  if (pair >= a.S * a.H) return;                       // wave-uniform; no workgroup barriers below
+  const int s = pair / a.H, h = pair - s * a.H, L = a.L, D = a.H * 64, ld = 3 * D, Lp = (L + 3) & ~3;
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (32 * NB * RS);
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)s * L * ld + h * 64;
+  const bf16_t* kp = qp + D;
+  const bf16_t* vp = qp + 2 * D;
+
+  stage_tile<NB>(vp, ld, L, Vs, lane);
+
+  // ---- S^T[jt][it] = K Q^T
+  f32x16_t sc[NB][NB];
+  {
+    bf16x8_t kf[NB][4], qf[NB][4];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[t][ks] = gfrag(kp, ld, 32 * t + l31, L, ks, half);
+        qf[t][ks] = gfrag(qp, ld, 32 * t + l31, L, ks, half);
+      }
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[jt][it][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[jt][ks], qf[it][ks], sc[jt][it], 0, 0, 0);
+      }
+  }
+  // additive key mask of this lane's keys (independent of the query tile)
+  float mk[NB][16];
+#pragma unroll
+  for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * jt + acc_row(r, half);
+      mk[jt][r] = a.mask ? a.mask[(size_t)s * L + min(j, L - 1)] : 0.f;
+    }
+  // V^T fragments: k-slot e of step ks <-> key 32 jt + 16 ks + 4 half + (e & 3) + 8 (e >> 2), i.e. the
+  // keys this lane holds in accumulator registers 8 ks .. 8 ks + 7
+  wave_sync_lds();
+  bf16x8_t vf[2][NB][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r0 = 32 * jt + 16 * ks + 4 * half;
+        vf[dt][jt][ks] = tr_frag(tr_addr(Vs, RS * 2, r0, dt, lane), tr_addr(Vs, RS * 2, r0 + 8, dt, lane));
+      }
+
+  DropCtx drop(a.dropout);
+  f32x16_t cx[2][NB];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    const int i = 32 * it + l31;
+    float p[NB][16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * jt + acc_row(r, half);
+        const float v = j < L ? fmaf(sc[jt][it][r], a.scale, mk[jt][r]) : -3.0e38f;
+        p[jt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * jt + acc_row(r, half);
+        const float e = j < L ? __expf(p[jt][r] - mx) : 0.f;
+        p[jt][r] = e;
+        sum += e;
+      }
+    sum += xhalf(sum);
+    const float inv = 1.f / sum;
+    float* prow = a.probs ? a.probs + ((size_t)(s * a.H + h) * L + min(i, L - 1)) * L : nullptr;
+    const uint64_t drow = ((uint64_t)(s * a.H + h) * L + i) * (uint64_t)Lp;
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j0 = 32 * jt + 8 * q + 4 * half;
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (drop.on()) m = drop.mask4((drow + j0) >> 2);
+        const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pr = p[jt][4 * q + e] * inv;
+          if (prow && i < L && j0 + e < L) prow[j0 + e] = pr;
+          p[jt][4 * q + e] = pr * mm[e];
+        }
+      }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cx[dt][it][e] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          cx[dt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][jt][ks], pack8(&p[jt][8 * ks]), cx[dt][it], 0, 0, 0);
+    }
+  }
+  store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)s * L * D + h * 64, D, L, cx, lane);
+}
+
+template <int NB, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 32 * NB;
+  constexpr int PS = R + 8;                              // [query][key] bf16 row stride (elements)
+  constexpr int WAVE_BYTES = 3 * R * RS * 2 + 2 * R * PS * 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const int pair = blockIdx.x * WPB + wave;
+  if (pair >= a.S * a.H) return;
+  const int s = pair / a.H, h = pair - s * a.H, L = a.L, D = a.H * 64, ld = 3 * D, Lp = (L + 3) & ~3;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + wave * WAVE_BYTES);
+  bf16_t* Qs = Ks + R * RS;
+  bf16_t* Os = Qs + R * RS;
+  bf16_t* Pl = Os + R * RS;                              // dropped probabilities [i][j]
+  bf16_t* Sl = Pl + R * PS;                              // dS [i][j]
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)s * L * ld + h * 64;
+  const bf16_t* kp = qp + D;
+  const bf16_t* vp = qp + 2 * D;
+  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)s * L * D + h * 64;
+
+  stage_tile<NB>(kp, ld, L, Ks, lane);
+  stage_tile<NB>(qp, ld, L, Qs, lane);
+  stage_tile<NB>(op, D, L, Os, lane);
+
+  // ---- dP^T[jt][it] = V dO^T (dP w.r.t. the DROPPED probabilities)
+  f32x16_t dp[NB][NB];
+  {
+    bf16x8_t vf[NB][4];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) vf[t][ks] = gfrag(vp, ld, 32 * t + l31, L, ks, half);
+    wave_sync_lds();
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      bf16x8_t of[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) of[ks] = lfrag(Os, 32 * it + l31, ks, half);
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dp[jt][it][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jt][ks], of[ks], dp[jt][it], 0, 0, 0);
+      }
+    }
+  }
+  // K^T fragments for dQ (same key <-> k-slot assignment as the forward's V^T)
+  bf16x8_t kf[2][NB][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r0 = 32 * jt + 16 * ks + 4 * half;
+        kf[dt][jt][ks] = tr_frag(tr_addr(Ks, RS * 2, r0, dt, lane), tr_addr(Ks, RS * 2, r0 + 8, dt, lane));
+      }
+
+  DropCtx drop(a.dropout);
+  bf16_t* dq = static_cast<bf16_t*>(a.dqkv) + (size_t)s * L * ld + h * 64;
+  f32x16_t gq[2][NB];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    const int i = 32 * it + l31;
+    const float* prow = a.probs + ((size_t)(s * a.H + h) * L + min(i, L - 1)) * L;
+    const uint64_t drow = ((uint64_t)(s * a.H + h) * L + i) * (uint64_t)Lp;
+    float pr[NB][16], ds[NB][16];
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * jt + acc_row(r, half);
+        const float v = prow[min(j, L - 1)];
+        pr[jt][r] = (i < L && j < L) ? v : 0.f;
+      }
+    float delta = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j0 = 32 * jt + 8 * q + 4 * half;
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (drop.on()) m = drop.mask4((drow + j0) >> 2);
+        const float mm[4] = {m.x, m.y, m.z, m.w};
+        float pd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = dp[jt][it][4 * q + e] * mm[e];       // dP w.r.t. the softmax output
+          ds[jt][4 * q + e] = g;
+          delta = fmaf(g, pr[jt][4 * q + e], delta);
+          pd[e] = pr[jt][4 * q + e] * mm[e];
+        }
+        st_bf4(Pl + i * PS + j0, pd[0], pd[1], pd[2], pd[3]);
+      }
+    delta += xhalf(delta);
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[jt][r] = pr[jt][r] * (ds[jt][r] - delta) * a.scale;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        st_bf4(Sl + i * PS + 32 * jt + 8 * q + 4 * half, ds[jt][4 * q], ds[jt][4 * q + 1], ds[jt][4 * q + 2], ds[jt][4 * q + 3]);
+    }
+    // dQ^T[dt][it] = K^T dS^T, B straight from the registers
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gq[dt][it][e] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          gq[dt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[dt][jt][ks], pack8(&ds[jt][8 * ks]), gq[dt][it], 0, 0, 0);
+    }
+  }
+  store_headT<NB>(dq, ld, L, gq, lane);
+
+  // ---- dV^T = dO^T P_dropped, dK^T = Q^T dS: contraction over the queries, k-slot e of step ks <-> query
+  //      32 it + 16 ks + 8 half + e for both operands (two transpose reads of 4 rows each)
+  wave_sync_lds();
+  f32x16_t gv[2][NB], gk[2][NB];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { gv[dt][jt][e] = 0.f; gk[dt][jt][e] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < NB; ++it)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = 32 * it + 16 * ks + 8 * half;
+      bf16x8_t of[2], qf[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        of[dt] = tr_frag(tr_addr(Os, RS * 2, r0, dt, lane), tr_addr(Os, RS * 2, r0 + 4, dt, lane));
+        qf[dt] = tr_frag(tr_addr(Qs, RS * 2, r0, dt, lane), tr_addr(Qs, RS * 2, r0 + 4, dt, lane));
+      }
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt) {
+        const bf16x8_t pf = tr_frag(tr_addr(Pl, PS * 2, r0, jt, lane), tr_addr(Pl, PS * 2, r0 + 4, jt, lane));
+        const bf16x8_t sf = tr_frag(tr_addr(Sl, PS * 2, r0, jt, lane), tr_addr(Sl, PS * 2, r0 + 4, jt, lane));
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          gv[dt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[dt], pf, gv[dt][jt], 0, 0, 0);
+          gk[dt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[dt], sf, gk[dt][jt], 0, 0, 0);
+        }
+      }
+    }
+  store_headT<NB>(dq + D, ld, L, gk, lane);
+  store_headT<NB>(dq + 2 * D, ld, L, gv, lane);
+}
+
+template <int NB, int WPB>
+int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
+  constexpr int R = 32 * NB;
+  const int pairs = a.S * a.H;
+  const int grid = (pairs + WPB - 1) / WPB;
+  if (bwd) {
+    const size_t lds = (size_t)WPB * (3 * R * RS * 2 + 2 * R * (R + 8) * 2);
+    static bool set = false;
+    if (!set && lds > 65536) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      set = true;
+    }
+    hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB>), dim3(grid), dim3(64 * WPB), lds, s, a);
+  } else {
+    const size_t lds = (size_t)WPB * R * RS * 2;
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB>), dim3(grid), dim3(64 * WPB), lds, s, a);
+  }
+  return check_launch(bwd ? "hero_attention_bwd(mfma)" : "hero_attention_fwd(mfma)");
+}
+
+}  // namespace
+
+// bf16, 1 <= L <= 64.  Called by attention.hip's dispatcher.
+int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s) {
+  if (a.L <= 32) return launch<1, 4>(a, bwd, s);
+  return launch<2, 1>(a, bwd, s);
+}
+
+}  // namespace hero

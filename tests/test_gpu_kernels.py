@@ -153,7 +153,8 @@ def test_layernorm_fp32_in_bf16_out_and_tables(HF):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("S,L,H", [(3, 9, 2), (5, 24, 12), (2, 60, 12), (2, 100, 3), (1, 130, 2)])
+@pytest.mark.parametrize("S,L,H", [(3, 9, 2), (5, 24, 12), (2, 60, 12), (2, 100, 3), (1, 130, 2), (4, 15, 12),
+                                   (3, 32, 4), (2, 33, 2), (2, 64, 3), (41, 24, 12), (1, 1, 1)])
 def test_attention_fwd_bwd(HF, dtype, S, L, H):
     D = H * 64
     qkv = rnd(S * L, 3 * D, dtype=dtype, seed=1)
@@ -204,6 +205,30 @@ def test_attention_dropout_adjoint(HF, Lb):
     assert abs(kept - 0.9) < 0.01, kept
     vals = torch.unique(y)
     assert len(vals) == 2 and abs(vals.max().item() - 1 / 0.9) < 1e-5
+
+
+@pytest.mark.parametrize("S,L,H", [(5, 24, 3), (3, 15, 2), (2, 60, 2), (2, 37, 1)])
+def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
+    """The bf16 matrix-core attention kernels (L <= 64) and the fp32 VALU kernels draw the SAME dropout
+    mask for the same site (index = ((s*H+h)*L + q)*round_up(L,4) + k): forward and backward agree on
+    bf16-representable inputs within the bf16 tolerance, and the adjoint identity holds."""
+    D = H * 64
+    qkv16 = rnd(S * L, 3 * D, dtype=torch.bfloat16, seed=1)
+    dctx16 = rnd(S * L, D, dtype=torch.bfloat16, seed=2)
+    m = torch.ones(S, L)
+    m[0, L - 1] = 0
+    madd = ((1 - m) * -10000.0).cuda()
+    drop = HF.RNG.make(0.3, True, qkv16.device)
+    ctx16, probs16 = HF.k_attn_fwd(qkv16, madd, S, L, H, drop=drop)
+    ctx32, probs32 = HF.k_attn_fwd(qkv16.float(), madd, S, L, H, drop=drop)
+    torch.testing.assert_close(probs16, probs32, rtol=2e-2, atol=2e-3)
+    close(ctx16, ctx32, torch.bfloat16)
+    d16 = HF.k_attn_bwd(qkv16, probs32, dctx16, S, L, H, drop=drop)
+    d32 = HF.k_attn_bwd(qkv16.float(), probs32, dctx16.float(), S, L, H, drop=drop)
+    close(d16, d32, torch.bfloat16, scale=2)
+    lhs = (dctx16.float() * ctx16.float()).sum()
+    rhs = (d16[:, 2 * D:].float() * qkv16[:, 2 * D:].float()).sum()
+    torch.testing.assert_close(lhs, rhs, rtol=2e-2, atol=0.5)
 
 
 def test_ln_bwd_dropout_consistency(HF, Lb):

@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(HeroLnBwd a, float* p
 
 // out_k[c] = beta*out_k[c] + sum_b partial[b][k][c] for k = blockIdx.y (outputs may be NULL).
 // 16 float4 column groups x 16 partial-lanes per workgroup; fixed summation order.
+// gridDim.z > 1 (only with beta == 1): each z-slice folds its share of the partials and adds it with
+// fp32 atomics (8-way contention) - 8x the parallelism of the single-slice, deterministic form.
 __global__ __launch_bounds__(256) void colred_final3_kernel(const float* partial, float* o0, float* o1, float* o2, int cols,
                                                             int nblocks, float beta) {
   const int k = blockIdx.y;
@@ -235,9 +237,11 @@ __global__ __launch_bounds__(256) void colred_final3_kernel(const float* partial
   __shared__ float4 red[16][16];
   const int cg = threadIdx.x & 15, kl = threadIdx.x >> 4;
   const int c = (blockIdx.x * 16 + cg) * 4;
+  const int per = (nblocks + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < cols)
-    for (int b = kl; b < nblocks; b += 16) {
+    for (int b = b0 + kl; b < b1; b += 16) {
       const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)b * 3 + k) * cols + c);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -248,6 +252,10 @@ __global__ __launch_bounds__(256) void colred_final3_kernel(const float* partial
     for (int j = 1; j < 16; ++j) {
       const float4 v = red[j][cg];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (gridDim.z > 1) {
+      atomicAdd(out + c, s.x); atomicAdd(out + c + 1, s.y); atomicAdd(out + c + 2, s.z); atomicAdd(out + c + 3, s.w);
+      return;
     }
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (beta != 0.f) {
@@ -365,12 +373,12 @@ static int run_colred(const void* x, const void* dy, const float* mean, const fl
   ColRed a;
   a.x = x; a.dy = dy; a.mean = mean; a.rstd = rstd;
   a.rows = rows; a.cols = cols; a.ld = ld; a.dropout = dr;
+  a.og = x ? og : nullptr;
+  a.ob = ob;
   const int nchunks = chunking(rows, &a.rows_per_chunk);
   a.pb = static_cast<float*>(ws);
   a.pg = x ? a.pb + (size_t)nchunks * cols : nullptr;
-  a.atomic = 0;   // (fp32 atomics straight into the outputs were measured 3x SLOWER: 256-way contention)
-  a.og = x ? og : nullptr;
-  a.ob = ob;
+  a.atomic = 0;   // (fp32 atomics straight into the outputs were measured SLOWER, at 256-way and at 64-way contention)
   hipLaunchKernelGGL((colred_kernel<TX, T>), dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, a);
   int rc = check_launch("colred");
   if (rc || a.atomic) return rc;
@@ -450,7 +458,8 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
 #undef CALLF
     int rc = check_launch("hero_layernorm_bwd(fused)");
     if (rc) return rc;
-    hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 63) / 64, 3), dim3(256), 0, s, partial, a->dgamma, a->dbeta,
+    const int zs = (a->grad_beta == 1.f && nblk >= 128) ? 8 : 1;
+    hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 63) / 64, 3, zs), dim3(256), 0, s, partial, a->dgamma, a->dbeta,
                        a->dbias_in, a->cols, nblk, a->grad_beta);
     return check_launch("hero_layernorm_bwd(final3)");
   }
@@ -487,7 +496,7 @@ extern "C" int hero_colsum(const void* x, float* out, int rows, int cols, int ld
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeroDropout none = {nullptr, 0, 0, 1.f};
   if (rows <= 0) {
-    if (beta == 0.f) hipMemsetAsync(out, 0, sizeof(float) * cols, s);
+    if (beta == 0.f) (void)hipMemsetAsync(out, 0, sizeof(float) * cols, s);
     return HERO_OK;
   }
   if (dtype == HERO_F32) return run_colred<float, float>(nullptr, x, nullptr, nullptr, nullptr, out, rows, cols, ld, beta, none, workspace, s);

@@ -174,6 +174,10 @@ class GradSink:
             p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return p.grad
 
+    def dst_group(self, params):
+        """A single contiguous view over several parameters' gradients, or None (separate tensors)."""
+        return None
+
     def use(self, p):
         pass
 
@@ -309,10 +313,10 @@ def k_colsum(dy2, out=None, beta=0.0, col0=0, ncols=None):
     return out
 
 
-def acc_linear_grads(dy2, x2, weight, bias, col0=0):
+def acc_linear_grads(dy2, x2, weight, bias, col0=0, ncols=None):
     """weight.grad += dy^T x ; bias.grad += colsum(dy) straight into the gradient sink."""
-    N = weight.shape[0]
-    if weight.requires_grad:
+    N = ncols if ncols is not None else weight.shape[0]
+    if weight is not None and weight.requires_grad:
         k_wgrad(dy2, x2, out=SINK.dst(weight), beta=1.0, col0=col0, ncols=N)
         SINK.done(weight)
     if bias is not None and bias.requires_grad:
@@ -622,10 +626,22 @@ class CsrGatherSumFn(torch.autograd.Function):
 # Parameters of the blocks are always leaf nn.Parameters; their gradients go to the gradient sink
 # (accumulated in place by the kernels) and the functions return None for them.
 def _qkv_bwd(dqkv, x2, qkv_params, D):
+    """Parameter gradients of the fused QKV projection.  When the gradient sink keeps the three
+    weights (and the three biases) back to back, d[Wq;Wk;Wv] is ONE [3D, D] GEMM and d[bq;bk;bv] one
+    column sum; otherwise three of each."""
     wq, bq, wk, bk, wv, bv = qkv_params
-    acc_linear_grads(dqkv, x2, wq, bq, col0=0)
-    acc_linear_grads(dqkv, x2, wk, bk, col0=D)
-    acc_linear_grads(dqkv, x2, wv, bv, col0=2 * D)
+    ws, bs = (wq, wk, wv), (bq, bk, bv)
+    gw = SINK.dst_group(ws) if all(p.requires_grad for p in ws) else None
+    gb = SINK.dst_group(bs) if all(p.requires_grad for p in bs) else None
+    if gw is not None:
+        k_wgrad(dqkv, x2, out=gw, beta=1.0)
+    if gb is not None:
+        k_colsum(dqkv, out=gb.view(-1), beta=1.0)
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        acc_linear_grads(dqkv, x2, None if gw is not None else w, None if gb is not None else b, col0=i * D,
+                         ncols=D)
+    for p in (ws if gw is not None else ()) + (bs if gb is not None else ()):
+        SINK.done(p)
 
 
 class SelfAttentionFn(torch.autograd.Function):

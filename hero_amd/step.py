@@ -25,13 +25,26 @@ TVR_OPTS = dict(  # config/train-tvr-8gpu.json
     train_batch_size=32, dropout=0.1, lw_neg_q=8.0, lw_neg_ctx=8.0, lw_st_ed=0.01, margin=0.1)
 
 
+def qkv_groups(model):
+    """Gradient-arena groups: each attention block's query/key/value weights (and biases) back to
+    back, so that their gradients are one [3D, D] GEMM (+ one column sum) in the backward."""
+    from .model.layers import BertSelfAttention
+    groups = []
+    for m in model.modules():
+        if isinstance(m, BertSelfAttention):
+            groups.append((m.query.weight, m.key.weight, m.value.weight))
+            groups.append((m.query.bias, m.key.bias, m.value.bias))
+    return groups
+
+
 class TrainStep:
     def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False):
         self.model = model
         self.opts = SimpleNamespace(**{**TVR_OPTS, **(opts or {})})
         self.task = task
         self.optimizer = build_optimizer(model, self.opts)
-        self.arena = D.GradArena(list(model.parameters()), bucket_bytes=bucket_bytes)
+        self.arena = D.GradArena(list(model.parameters()), bucket_bytes=bucket_bytes,
+                                 groups=qkv_groups(model))
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152

@@ -93,7 +93,10 @@ class GradArena(HF.GradSink):
     optimiser or call `scale_()`.
     """
 
-    def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True):
+    def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True, groups=()):
+        """groups: tuples of parameters whose gradients must be CONTIGUOUS in the arena, in the given
+        order (e.g. an attention block's query/key/value weights: the backward then writes
+        d[Wq;Wk;Wv] with one GEMM instead of three, see hero_amd.functional._qkv_bwd)."""
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -101,15 +104,24 @@ class GradArena(HF.GradSink):
         self.slices = {}
         self.buckets = []            # [start, end, n_params]
         self.bucket_of = {}
+        group_of = {}
+        for g in groups:
+            g = tuple(g)
+            if all(q.requires_grad and q.numel() % 4 == 0 for q in g):
+                for q in g:
+                    group_of[q] = g
         off, start, count = 0, 0, 0
         for p in reversed(self.params):
-            n = p.numel()
-            pad = (-off) % 4                 # keep every slice 16-byte aligned for the kernels
-            off += pad
-            self.slices[p] = (off, off + n)
-            self.bucket_of[p] = len(self.buckets)
-            off += n
-            count += 1
+            if p in self.slices:
+                continue                     # already placed with its group
+            for q in group_of.get(p, (p,)):
+                n = q.numel()
+                pad = (-off) % 4             # keep every slice 16-byte aligned for the kernels
+                off += pad
+                self.slices[q] = (off, off + n)
+                self.bucket_of[q] = len(self.buckets)
+                off += n
+                count += 1
             if (off - start) * 4 >= bucket_bytes:
                 self.buckets.append([start, off, count])
                 start, count = off, 0
@@ -141,6 +153,19 @@ class GradArena(HF.GradSink):
         if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + sl[0] * 4:
             p.grad = self.flat[sl[0]:sl[1]].view_as(p)
         return p.grad
+
+    def dst_group(self, params):
+        """One [sum(rows), cols] view over the gradients of `params` if they lie back to back in the
+        arena (see `groups`), else None."""
+        sl = [self.slices.get(p) for p in params]
+        if any(x is None for x in sl) or any(sl[i][1] != sl[i + 1][0] for i in range(len(sl) - 1)):
+            return None
+        for p in params:
+            self.dst(p)
+        tail = params[0].shape[1:]
+        if any(p.shape[1:] != tail for p in params):
+            return None
+        return self.flat[sl[0][0]:sl[-1][1]].view((-1,) + tuple(tail))
 
     def use(self, p):
         self._uses[p] = self._uses.get(p, 0) + 1

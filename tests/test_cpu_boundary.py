@@ -146,3 +146,30 @@ def test_synth_batch_contract():
             if not fr:
                 assert r["f_attn_masks"][row, 0] == 0 and r["f_v_feats"][row].abs().sum() == 0
             row += 1
+
+
+def test_grad_arena_groups_are_contiguous():
+    """GradArena(groups=...) lays the grouped parameters back to back (in group order) wherever the
+    first member falls, keeps 16-byte alignment, and dst_group() returns one stacked view of them."""
+    import torch
+    from hero_amd.utils import distributed as D
+    from hero_amd import functional as HF
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in [(8, 4), (6,), (8, 4), (3,), (8, 4), (8,), (8,), (8,)]]
+    wq, odd, wk, odd2, wv, bq, bk, bv = ps
+    try:
+        arena = D.GradArena(ps, bucket_bytes=64, groups=[(wq, wk, wv), (bq, bk, bv)])
+        g = arena.dst_group((wq, wk, wv))
+        assert g is not None and g.shape == (24, 4)
+        g.copy_(torch.arange(96.0).view(24, 4))
+        assert torch.equal(wq.grad, g[:8]) and torch.equal(wk.grad, g[8:16]) and torch.equal(wv.grad, g[16:])
+        gb = arena.dst_group((bq, bk, bv))
+        assert gb is not None and gb.shape == (24,)
+        assert arena.dst_group((wq, wv)) is None and arena.dst_group((odd, odd2)) is None
+        for p in ps:
+            s, e = arena.slices[p]
+            assert s % 4 == 0 and e - s == p.numel()
+        spans = sorted(arena.slices[p] for p in ps)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))          # no overlap
+        assert sum(b[2] for b in arena.buckets) == len(ps)
+    finally:
+        HF.set_grad_sink(None)

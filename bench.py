@@ -109,11 +109,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if os.environ.get("HERO_BENCH_ONE_DEVICE"):      # plumbing check of the N>1 path on a 1-GPU box
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("HERO_BENCH_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
 
     import hero_amd
     from hero_amd import _lib as L

@@ -127,7 +127,7 @@ def lib():
                                     C.c_void_p]
         L.hero_gelu_bwd.argtypes = L.hero_relu_bwd.argtypes
         L.hero_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-        L.hero_sumsq.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.hero_sumsq.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hero_adamw.argtypes = [C.POINTER(AdamW), C.c_void_p]
         L.hero_adamw_multi.argtypes = [C.POINTER(AdamWMulti), C.c_void_p]
         _lib = L

@@ -137,7 +137,18 @@ __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float* out) 
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);   // per-block partial
+}
+// fixed-order fold of the partials: the gradient norm is bit-identical on every data-parallel rank
+// (an atomicAdd fold made replicas drift apart by an ulp per step through the clipping factor)
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nblocks, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ void adamw_kernel(HeroAdamW a, float bc1, float bc2) {
@@ -362,11 +373,13 @@ extern "C" int hero_add(const void* a, const void* b, void* y, size_t n, int dty
   return check_launch("hero_add");
 }
 
-extern "C" int hero_sumsq(const float* g, size_t n, float* sumsq, hero_stream_t stream) {
-  HERO_REQUIRE(g && sumsq, "hero_sumsq: null pointer");
+extern "C" int hero_sumsq(const float* g, size_t n, float* sumsq, float* workspace, hero_stream_t stream) {
+  HERO_REQUIRE(g && sumsq && workspace, "hero_sumsq: null pointer");
   if (n == 0) return HERO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, s, g, n, sumsq);
+  const int nb = grid_for(n >> 2);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, g, n, workspace);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, workspace, nb, sumsq);
   return check_launch("hero_sumsq");
 }
 

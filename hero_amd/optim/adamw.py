@@ -33,14 +33,17 @@ class AdamW(Optimizer):
         """Device scalar = sum of squared gradients (one launch over a flat arena if given)."""
         dev = next(p for g in self.param_groups for p in g["params"]).device
         out = torch.zeros(1, dtype=torch.float32, device=dev)
+        if getattr(self, "_sumsq_ws", None) is None or self._sumsq_ws.device != dev:
+            self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=dev)
+        ws = self._sumsq_ws
         if flat is not None:
-            L.check(L.lib().hero_sumsq(L.ptr(flat), flat.numel(), L.ptr(out), L.stream()))
+            L.check(L.lib().hero_sumsq(L.ptr(flat), flat.numel(), L.ptr(out), L.ptr(ws), L.stream()))
             return out
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is not None:
                     gr = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                    L.check(L.lib().hero_sumsq(L.ptr(gr), gr.numel(), L.ptr(out), L.stream()))
+                    L.check(L.lib().hero_sumsq(L.ptr(gr), gr.numel(), L.ptr(out), L.ptr(ws), L.stream()))
         return out
 
     # ---- descriptor table ------------------------------------------------------------------------

@@ -197,8 +197,10 @@ int hero_add(const void* a, const void* b, void* y, size_t n, int dtype, hero_st
 /* Optimiser — optim/adamw.py:43-106 + clip_grad_norm_ (train_vcmr.py:257-260) over flat fp32   */
 /* parameter / gradient arenas.                                                                 */
 /* ------------------------------------------------------------------------------------------ */
-/* sumsq[0] += sum g^2 (fp32 device scalar; caller zeroes it).                                   */
-int hero_sumsq(const float* g, size_t n, float* sumsq, hero_stream_t stream);
+/* sumsq[0] += sum g^2 (fp32 device scalar; caller zeroes it).  Deterministic (fixed summation  */
+/* order): data-parallel replicas must derive the SAME clipping factor from the same gradients.  */
+/* workspace: >= 2048 floats of device scratch.                                                  */
+int hero_sumsq(const float* g, size_t n, float* sumsq, float* workspace, hero_stream_t stream);
 typedef struct HeroAdamW {
   float* p;
   const float* g;

@@ -1,0 +1,84 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a 2-process data-parallel run with the REAL
+HIP kernels.  The GPU box has one MI355X, so both ranks use cuda:0 and the collectives go through
+gloo (host-staged) instead of RCCL; everything above the transport - GradArena's use/done counting
+from the HIP backward, bucket launches, averaging folded into the optimiser, cross-rank negatives -
+is the production code path of bench.py --gpus N."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.step import TrainStep
+    from hero_amd.synth import make_batch
+    from hero_amd.utils.misc import set_dropout
+    hero_amd.set_compute_dtype(torch.float32)
+    from tests.util import load_tiny
+    model, _, _ = load_tiny("cuda")
+    if rank == 1:                                      # the constructor's broadcast from rank 0 must undo this
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01)
+    set_dropout(model, 0.0)
+    model.train()
+    trainer = TrainStep(model, opts={"gradient_accumulation_steps": 2, "learning_rate": 1e-3}, use_graph=False,
+                        bucket_bytes=64 << 10)        # small buckets -> many overlapped all-reduces
+    named = dict(model.named_parameters())
+    # (1) parameters were broadcast from rank 0
+    chk = torch.stack([p.detach().double().sum() for p in named.values()])
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    assert torch.equal(both[0], both[1]), "parameter broadcast failed"
+
+    batch = make_batch("D1", vfeat_dim=96, vocab=160, seed=1 + rank, device=dev)
+    # (2) local gradients of two accumulated micro-steps WITHOUT synchronisation
+    trainer.arena.zero()
+    for _ in range(2):
+        trainer.arena.set_sync(False)
+        trainer._fwd_bwd(batch)
+        trainer.arena.finish()
+    local = trainer.arena.flat.clone()
+    gl = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gl, local)
+    want_sum = gl[0] + gl[1]
+    # (3) the same two micro-steps through the production path: buckets all-reduced from the hooks
+    trainer.arena.zero()
+    trainer.arena.set_sync(False)
+    trainer._fwd_bwd(batch)
+    trainer.arena.set_sync(True)
+    trainer._fwd_bwd(batch)
+    trainer.arena.finish()
+    got = trainer.arena.flat.clone()
+    err = (got - want_sum).abs().max().item() / max(want_sum.abs().max().item(), 1e-12)
+    assert err < 1e-5, "bucketed all-reduce != sum of local gradients (rel %g)" % err
+    nb = len(trainer.arena.buckets)
+    # (4) full optimiser steps keep the replicas identical
+    trainer.arena.zero()
+    losses = []
+    for _ in range(4):
+        losses.append(float(trainer.micro_step(batch)))
+    chk = torch.stack([p.detach().double().sum() for p in named.values()])
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    assert torch.equal(both[0], both[1]), "replicas diverged after optimiser steps"
+    assert all(l == l and abs(l) < 1e4 for l in losses)
+    json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses},
+              open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

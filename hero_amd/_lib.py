@@ -159,7 +159,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw hipStream_t of torch's current stream (the private fast accessors cost ~0.3 us; the
+    public `torch.cuda.current_stream().cuda_stream` ~10 us, x165 launches per micro-step)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

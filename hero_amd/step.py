@@ -57,9 +57,10 @@ class TrainStep:
     # ---- pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch):
         HF.advance_seed()
-        l_st_ed, l_ctx, l_q = self.model(batch, task=self.task, compute_loss=True)
-        loss = (l_st_ed + l_ctx + l_q).mean()
-        loss.backward()
+        with HF.weights_frozen():                   # inside the step only the optimiser changes weights
+            l_st_ed, l_ctx, l_q = self.model(batch, task=self.task, compute_loss=True)
+            loss = (l_st_ed + l_ctx + l_q).mean()
+            loss.backward()
         return loss.detach()
 
     def _optimise(self, device_state):

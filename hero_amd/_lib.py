@@ -21,6 +21,8 @@ EXPORTS = [
     "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
+    "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
+    "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
 ]
 
 
@@ -84,6 +86,41 @@ class AdamWMulti(C.Structure):
                 ("step_ptr", C.c_void_p), ("lr_ptr", C.c_void_p)]
 
 
+class QueryPool(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("mask", C.c_void_p), ("w", C.c_void_p), ("pooled", C.c_void_p),
+                ("att", C.c_void_p), ("dpooled", C.c_void_p), ("dq", C.c_void_p), ("dw", C.c_void_p),
+                ("B", C.c_int), ("L", C.c_int), ("D", C.c_int), ("dtype", C.c_int)]
+
+
+class RowNorm(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("rnorm", C.c_void_p), ("dy", C.c_void_p),
+                ("dx", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("x_dtype", C.c_int),
+                ("eps", C.c_float)]
+
+
+class ScoreMax(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("mask", C.c_void_p), ("out", C.c_void_p), ("arg", C.c_void_p),
+                ("ds_ctx", C.c_void_p), ("ds_q", C.c_void_p), ("gc", C.c_void_p), ("gq", C.c_void_p),
+                ("qn", C.c_void_p), ("cn", C.c_void_p), ("dqn", C.c_void_p), ("dcn", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("L", C.c_int), ("D", C.c_int), ("n0", C.c_int),
+                ("n_own", C.c_int), ("ld_s", C.c_int)]
+
+
+class RankLoss(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("loss_ctx_rows", C.c_void_p), ("loss_q_rows", C.c_void_p),
+                ("ds_ctx", C.c_void_p), ("ds_q", C.c_void_p), ("nq", C.c_int), ("nv", C.c_int),
+                ("margin", C.c_float), ("lse", C.c_int), ("hard", C.c_int), ("pool", C.c_int),
+                ("hard_w", C.c_float), ("easy_w", C.c_float)]
+
+
+class StEd(C.Structure):
+    _fields_ = [("q2", C.c_void_p), ("ctx", C.c_void_p), ("mask", C.c_void_p), ("w_st", C.c_void_p),
+                ("w_ed", C.c_void_p), ("targets", C.c_void_p), ("loss_rows", C.c_void_p),
+                ("p_st", C.c_void_p), ("p_ed", C.c_void_p), ("sim", C.c_void_p), ("g", C.c_void_p),
+                ("dq2", C.c_void_p), ("dctx", C.c_void_p), ("dw_st", C.c_void_p), ("dw_ed", C.c_void_p),
+                ("B", C.c_int), ("L", C.c_int), ("D", C.c_int), ("K", C.c_int), ("dtype", C.c_int)]
+
+
 _lib = None
 
 
@@ -130,6 +167,11 @@ def lib():
         L.hero_sumsq.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hero_adamw.argtypes = [C.POINTER(AdamW), C.c_void_p]
         L.hero_adamw_multi.argtypes = [C.POINTER(AdamWMulti), C.c_void_p]
+        for fn, st in (("hero_query_pool_fwd", QueryPool), ("hero_query_pool_bwd", QueryPool),
+                       ("hero_rownorm_fwd", RowNorm), ("hero_rownorm_bwd", RowNorm),
+                       ("hero_score_max_fwd", ScoreMax), ("hero_score_max_bwd", ScoreMax),
+                       ("hero_rank_loss", RankLoss), ("hero_st_ed_fwd", StEd), ("hero_st_ed_bwd", StEd)):
+            getattr(L, fn).argtypes = [C.POINTER(st), C.c_void_p]
         _lib = L
     return _lib
 

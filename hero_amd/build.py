@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libhero_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "layernorm.hip", "attention.hip", "attention_mfma.hip", "rows.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "layernorm.hip", "attention.hip", "attention_mfma.hip", "rows.hip", "head.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

@@ -242,9 +242,15 @@ class QueryFeatEncoder(nn.Module):
         pooled = torch.einsum("blm,bld->bmd", att, query)[:, 0]
         return (pooled, att) if return_modular_att else pooled
 
+    fused_pool = True       # masked softmax pooling as one HIP kernel (hero_query_pool_*)
+
     def forward(self, query_feat, query_attn_mask, query_pos_ids=None):
         h = self.query_pos_embed(self.query_input_proj(query_feat), query_pos_ids)
         m = query_attn_mask.to(torch.float32)
         ext = ((1.0 - m) * -10000.0)[:, None, None, :]
-        attended = HF.cast(self.query_self_attention(h, ext)[0], torch.float32)
+        attended = self.query_self_attention(h, ext)[0]
+        if self.modularized and self.fused_pool:
+            from ..head import QueryPoolFn
+            return QueryPoolFn.apply(attended, m, self.modular_vector_mapping.weight)
+        attended = HF.cast(attended, torch.float32)
         return self.get_modularized_queries(attended, m) if self.modularized else attended

@@ -11,6 +11,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import functional as HF
 from ..utils import distributed as dist_utils
 from .encoder import QueryFeatEncoder
 from .model import HeroModel
@@ -34,6 +35,7 @@ class HeroForPretraining(HeroModel):
         self.drop_svmr_prob = drop_svmr_prob
         self.gather_gpus = True
         self.fuse_query_pass = True   # subtitle rows and query rows share the cross-modal layer launches
+        self.fused_head = True        # loss head on the hero_* head kernels when the configuration allows
         self.video_query_linear = nn.Linear(config.q_config.hidden_size, config.c_config.hidden_size)
         conv = dict(in_channels=1, out_channels=1, kernel_size=conv_kernel_size, stride=conv_stride,
                     padding=conv_kernel_size // 2, bias=False)
@@ -67,6 +69,9 @@ class HeroForPretraining(HeroModel):
                 batch["query_input_ids"], batch["query_pos_ids"], batch["query_attn_masks"],
                 attn_layer=self.q_feat_attn)
 
+        if compute_loss and self._head_is_fusable(frame_embeddings, modularized_query):
+            return self._fused_losses(batch, frame_embeddings, modularized_query)
+
         q2video_scores = st_prob = ed_prob = None
         if self.lw_st_ed != 0:
             if random.random() > self.drop_svmr_prob or not self.training:
@@ -94,6 +99,38 @@ class HeroForPretraining(HeroModel):
                 self.lw_neg_q * loss_neg_q)
 
     # ------------------------------------------------------------------------------------------
+    def _head_is_fusable(self, frame_embeddings, modularized_query):
+        """The HIP head covers the training configuration: 'mean' reduction, all in-batch negatives,
+        hinge / lse, matched (query, video) pairs, stride-1 odd kernels."""
+        convs = (self.video_st_predictor, self.video_ed_predictor)
+        nv = frame_embeddings.shape[0] * (dist_utils.world_size() if self.gather_gpus else 1)
+        return (self.fused_head and self.training and frame_embeddings.is_cuda and self.use_all_neg
+                and self.ranking_loss_type in ("hinge", "lse")
+                and frame_embeddings.shape[0] == modularized_query.shape[0]
+                and (nv > 1 or (self.lw_neg_ctx == 0 and self.lw_neg_q == 0))
+                and all(c.stride[0] == 1 and c.kernel_size[0] % 2 == 1 and c.kernel_size[0] <= 15
+                        for c in convs))
+
+    def _fused_losses(self, batch, frame_embeddings, modularized_query):
+        from ..head import RowNormFn, StEdLossFn, VideoRankLossFn
+        z = frame_embeddings.new_zeros((), dtype=torch.float32)
+        loss_st_ed, loss_neg_ctx, loss_neg_q = z, z, z
+        cmask = batch["c_attn_masks"]
+        if self.lw_st_ed != 0 and random.random() > self.drop_svmr_prob:       # model/pretrain.py:74-75
+            q2 = HF.linear(modularized_query, self.video_query_linear.weight, self.video_query_linear.bias)
+            loss_st_ed = StEdLossFn.apply(q2, frame_embeddings, cmask, self.video_st_predictor.weight,
+                                          self.video_ed_predictor.weight, batch["targets"])
+        if self.lw_neg_ctx != 0 or self.lw_neg_q != 0:
+            qn = RowNormFn.apply(modularized_query, 1e-5)
+            cn = RowNormFn.apply(frame_embeddings, 1e-5)
+            own = (0, cn.shape[0])
+            if self.gather_gpus and dist_utils.world_size() > 1:
+                qn, cn, cmask, own = dist_utils.gather_negatives(qn, cn, cmask, return_own=True)
+            loss_neg_ctx, loss_neg_q = VideoRankLossFn.apply(
+                qn, cn, cmask, own, float(self.margin), self.ranking_loss_type == "lse",
+                bool(self.use_hard_negative), int(self.hard_pool_size), float(self.hard_neg_weight))
+        return (self.lw_st_ed * loss_st_ed, self.lw_neg_ctx * loss_neg_ctx, self.lw_neg_q * loss_neg_q)
+
     @staticmethod
     def _conv5(conv, x):
         """nn.Conv1d(1, 1, k, padding=k//2, bias=False) on (N, 1, L) as unfold + dot: a handful of

@@ -253,9 +253,10 @@ class _AllGatherRows(torch.autograd.Function):
         return grad.narrow(0, ctx.offset, ctx.dim), None
 
 
-def gather_negatives(query, context, context_mask):
+def gather_negatives(query, context, context_mask, return_own=False):
     """All-gather (queries, L2-normalised contexts, masks) across ranks, padding contexts to the
-    global max clip length.  ONE small integer all-gather carries every size needed."""
+    global max clip length.  ONE small integer all-gather carries every size needed.
+    return_own: also return (first video, number of videos) of this rank inside the gathered set."""
     n = world_size()
     meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]],
                         dtype=torch.int64, device=query.device)
@@ -272,6 +273,8 @@ def gather_negatives(query, context, context_mask):
     q = _AllGatherRows.apply(query.contiguous(), nq)
     c = _AllGatherRows.apply(context.contiguous(), nv)
     m = _AllGatherRows.apply(context_mask.contiguous(), nv)
+    if return_own:
+        return q, c, m, (sum(nv[:rank()]), nv[rank()])
     return q, c, m
 
 

@@ -249,6 +249,116 @@ typedef struct HeroAdamWMulti {
 int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream);
 int hero_adamw_multi_chunk(void);
 
+/* ------------------------------------------------------------------------------------------ */
+/* VSM / VCMR task head - model/pretrain.py:62-116,128-201,203-292,  */
+/* model/encoder.py:460-471.  The few hundred tiny fp32 tensor ops between the encoders and the  */
+/* three loss scalars as a dozen kernels.  Every op has its forward and backward here; the two   */
+/* dense contractions in between (video_query_linear, normalised query x context scores) are    */
+/* hero_gemm calls.  All row-major, fp32 unless a dtype is given.                                */
+/* ------------------------------------------------------------------------------------------ */
+/* Query pooling (QueryFeatEncoder.get_modularized_queries, model/encoder.py:460-471):           */
+/*   sc[b,l] = <q[b,l,:], w>; att = softmax_l(sc*mask + (1-mask)*-1e4); pooled = sum_l att*q.    */
+typedef struct HeroQueryPool {
+  const void* q;          /* [B, L, D] dtype                                                    */
+  const float* mask;      /* [B, L] 0/1                                                         */
+  const float* w;         /* [D] modular_vector_mapping.weight                                  */
+  float* pooled;          /* fwd out [B, D]                                                     */
+  float* att;             /* fwd out / bwd in [B, L]                                            */
+  const float* dpooled;   /* bwd in [B, D]                                                      */
+  void* dq;               /* bwd out [B, L, D] dtype                                            */
+  float* dw;              /* bwd out [D], ACCUMULATED (+=)                                      */
+  int B, L, D, dtype;
+} HeroQueryPool;
+int hero_query_pool_fwd(const HeroQueryPool* a, hero_stream_t stream);
+int hero_query_pool_bwd(const HeroQueryPool* a, hero_stream_t stream);
+
+/* F.normalize(x, dim=-1, eps) (model/pretrain.py:370-371): y = x / max(||x||_2, eps).           */
+/* rnorm[r] = 1/max(||x_r||, eps), negated when the clamp was active (backward then skips the   */
+/* projection term).                                                                            */
+typedef struct HeroRowNorm {
+  const void* x;          /* [rows, cols] x_dtype                                               */
+  float* y;               /* fwd out [rows, cols] fp32                                          */
+  float* rnorm;           /* fwd out / bwd in [rows]                                            */
+  const float* dy;        /* bwd in [rows, cols] fp32                                           */
+  void* dx;               /* bwd out [rows, cols] x_dtype                                       */
+  int rows, cols, x_dtype;
+  float eps;
+} HeroRowNorm;
+int hero_rownorm_fwd(const HeroRowNorm* a, hero_stream_t stream);
+int hero_rownorm_bwd(const HeroRowNorm* a, hero_stream_t stream);
+
+/* Video-level scores (model/pretrain.py:364-382): s[m, n*L + l] = <qn[m], cn[n, l]> comes from  */
+/* hero_gemm; this is mask_logits + max over l:  out[m,n] = max_l (s*mask[n,l] + (1-mask)*-1e4). */
+/* Backward: g[m,n] = gc[0]*ds_ctx[m,n] + gq[0]*ds_q[m,n] (the ranking loss' two gradient        */
+/* matrices and the upstream gradients of its two scalars) flows to the arg-max entry only:     */
+/*   dqn[m,:]  = sum_n g*mask[n,arg]*cn[n,arg,:];   dcn[n,arg,:] += g*mask*qn[m,:]  for          */
+/* n in [n0, n0+n_own) (a data-parallel rank only needs its own videos' rows; dcn is            */
+/* [n_own*L, D] and is fully written).                                                          */
+typedef struct HeroScoreMax {
+  const float* s;         /* [M, N*L], row stride ld_s >= N*L                                   */
+  const float* mask;      /* [N, L] 0/1                                                         */
+  float* out;             /* fwd out [M, N]                                                     */
+  int32_t* arg;           /* fwd out / bwd in [M, N]                                            */
+  const float* ds_ctx;    /* bwd in [M, N]                                                      */
+  const float* ds_q;      /* bwd in [M, N]                                                      */
+  const float* gc;        /* bwd in: device scalar                                              */
+  const float* gq;        /* bwd in: device scalar                                              */
+  const float* qn;        /* bwd in [M, D]                                                      */
+  const float* cn;        /* bwd in [N*L, D]                                                    */
+  float* dqn;             /* bwd out [M, D]                                                     */
+  float* dcn;             /* bwd out [n_own*L, D]                                               */
+  int M, N, L, D, n0, n_own, ld_s;
+} HeroScoreMax;
+int hero_score_max_fwd(const HeroScoreMax* a, hero_stream_t stream);
+int hero_score_max_bwd(const HeroScoreMax* a, hero_stream_t stream);
+
+/* In-batch ranking loss over ALL negatives (get_video_level_loss, use_all_neg=True,            */
+/* model/pretrain.py:203-264): query m belongs to video m / (nq/nv).  loss_ctx_rows[m] = mean    */
+/* over the other videos n of w*rl(s[m,own], s[m,n]); loss_q_rows[m] = mean over the queries m2  */
+/* of other videos of w*rl(s[m,own], s[m2,own]); rl = hinge(margin) or log1p(exp(neg-pos));      */
+/* w = 1, or with hard negatives hard_w for the `pool` largest negatives of that row and easy_w  */
+/* for the rest.  ds_ctx / ds_q = gradients of mean(loss_ctx_rows) / mean(loss_q_rows) w.r.t. s  */
+/* (both fully written).                                                                        */
+typedef struct HeroRankLoss {
+  const float* s;         /* [nq, nv]                                                           */
+  float* loss_ctx_rows;   /* [nq]                                                               */
+  float* loss_q_rows;     /* [nq]                                                               */
+  float* ds_ctx;          /* [nq, nv]                                                           */
+  float* ds_q;            /* [nq, nv]                                                           */
+  int nq, nv;
+  float margin;
+  int lse;                /* 0 hinge, 1 lse                                                     */
+  int hard;               /* use_hard_negative                                                  */
+  int pool;               /* hard_pool_size                                                     */
+  float hard_w, easy_w;   /* hard_neg_weight, 0.1                                               */
+} HeroRankLoss;
+int hero_rank_loss(const HeroRankLoss* a, hero_stream_t stream);
+
+/* Start / end localisation (model/pretrain.py:128-166, 96-110): sim[b,l] = <q2[b], ctx[b,l]>,    */
+/* st/ed = Conv1d(1,1,K,pad=K/2,no bias)(sim), mask_logits, cross-entropy against targets[b,0/1] */
+/* (ignore_index -1, mean over the valid rows of each).  loss_rows[b] = ce_st[b]/n_st +           */
+/* ce_ed[b]/n_ed (sum over b = the reference's loss_st_ed).                                      */
+typedef struct HeroStEd {
+  const float* q2;        /* [B, D] video_query_linear(modularized query)                       */
+  const void* ctx;        /* [B, L, D] dtype: frame embeddings                                  */
+  const float* mask;      /* [B, L] 0/1                                                         */
+  const float* w_st;      /* [K]                                                                */
+  const float* w_ed;      /* [K]                                                                */
+  const int64_t* targets; /* [B, 2]                                                             */
+  float* loss_rows;       /* fwd out [B]                                                        */
+  float* p_st;            /* fwd out / bwd in [B, L] softmax                                    */
+  float* p_ed;            /* fwd out / bwd in [B, L]                                            */
+  float* sim;             /* fwd out / bwd in [B, L]                                            */
+  const float* g;         /* bwd in: device scalar, upstream gradient of sum(loss_rows)         */
+  float* dq2;             /* bwd out [B, D]                                                     */
+  void* dctx;             /* bwd out [B, L, D] dtype                                            */
+  float* dw_st;           /* bwd out [K], ACCUMULATED (+=)                                      */
+  float* dw_ed;           /* bwd out [K], ACCUMULATED (+=)                                      */
+  int B, L, D, K, dtype;
+} HeroStEd;
+int hero_st_ed_fwd(const HeroStEd* a, hero_stream_t stream);
+int hero_st_ed_bwd(const HeroStEd* a, hero_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,15 +253,29 @@ class _AllGatherRows(torch.autograd.Function):
         return grad.narrow(0, ctx.offset, ctx.dim), None
 
 
+_HOST_GROUP = [None, None]
+
+
+def _host_group():
+    """A gloo process group for small host-side metadata (None = the default group when that one
+    already is gloo)."""
+    pg = dist.distributed_c10d._get_default_group()
+    if _HOST_GROUP[0] is not pg:
+        _HOST_GROUP[0] = pg
+        _HOST_GROUP[1] = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _HOST_GROUP[1]
+
+
 def gather_negatives(query, context, context_mask, return_own=False):
     """All-gather (queries, L2-normalised contexts, masks) across ranks, padding contexts to the
     global max clip length.  ONE small integer all-gather carries every size needed.
     return_own: also return (first video, number of videos) of this rank inside the gathered set."""
     n = world_size()
-    meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]],
-                        dtype=torch.int64, device=query.device)
+    # the sizes are host values (tensor shapes): exchange them on the host (gloo side group) so the
+    # forward pass has no device synchronisation in it
+    meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]], dtype=torch.int64)
     metas = [torch.empty_like(meta) for _ in range(n)]
-    dist.all_gather(metas, meta)
+    dist.all_gather(metas, meta, group=_host_group())
     metas = torch.stack(metas).tolist()
     nq = [m[0] for m in metas]
     nv = [m[1] for m in metas]

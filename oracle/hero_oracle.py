@@ -115,8 +115,8 @@ def sub_embeddings(ids, pos_ids, P, prefix, p_drop=0.0):
 
 def img_embeddings(feat, pos_ids, type_row, P, prefix, img_masks=None, p_drop=0.0):
     """embed.py:102-117."""
-    if img_masks is not None:
-        feat = feat + P[prefix + ".mask_embedding.weight"][img_masks.long()]
+    if img_masks is not None:   # nn.Embedding(2, D, padding_idx=0): row 0 receives no gradient (embed.py:96)
+        feat = feat + F.embedding(img_masks.long(), P[prefix + ".mask_embedding.weight"], padding_idx=0)
     t = linear(layer_norm(feat, P, prefix + ".img_LayerNorm", 1e-5),
                P, prefix + ".img_linear")
     e = t + P[prefix + ".position_embeddings.weight"][pos_ids] + type_row
@@ -199,6 +199,69 @@ def forward_repr(batch, P, cfg, encode_clip=True, p_drop=0.0, taps=None):
     if not encode_clip:
         return pre
     return c_encoder(pre, batch["c_attn_masks"], P, cfg, p_drop=p_drop)
+
+
+# --------------------------------------------------------------------------- #
+# pre-training heads (BASELINE.json configs[3]): MLM, MFM, FOM
+# pinned by tests/golden/case_pretrain.npz (tests/golden/make_golden_pretrain.py)
+# --------------------------------------------------------------------------- #
+def lm_head(x, P, prefix="v_encoder.f_encoder.lm_head"):
+    """BertLMPredictionHead (layers.py:330-354): dense -> gelu -> LN(1e-5) -> tied decoder + bias."""
+    h = layer_norm(gelu_erf(linear(x, P, prefix + ".dense")), P, prefix + ".LayerNorm", 1e-5)
+    return h @ P[prefix + ".decoder.weight"].t() + P[prefix + ".bias"]
+
+
+def mlm_scores(batch, P, cfg, prefix="v_encoder.f_encoder"):
+    """CrossModalTrm.forward_mlm (encoder.py:355-374): scores of the masked positions only."""
+    b = {"f_sub_input_ids": batch["input_ids"], "f_sub_pos_ids": batch["position_ids"],
+         "f_v_feats": batch["v_feat"], "f_v_pos_ids": batch["f_pos_ids"],
+         "f_attn_masks": batch["attn_masks"], "f_gather_index": batch["gather_index"]}
+    seq = f_encoder_repr(b, P, cfg, prefix)
+    return lm_head(seq[batch["txt_mask_tgt"]], P, prefix + ".lm_head")
+
+
+def mlm_loss(batch, P, cfg):
+    return F.cross_entropy(mlm_scores(batch, P, cfg), batch["txt_labels"], reduction="none")
+
+
+def feat_regress(x, P, prefix="v_encoder.feat_regress"):
+    """FrameFeatureRegression (model.py:104-114): Linear -> GELU -> LN(1e-5) -> Linear."""
+    h = layer_norm(gelu_erf(linear(x, P, prefix + ".net.0")), P, prefix + ".net.2", 1e-5)
+    return linear(h, P, prefix + ".net.3")
+
+
+def mfm_loss(batch, P, cfg, loss="nce", nce_temp=1.0):
+    """HierarchicalVlModel.forward_mfm / mfm_nce (model.py:239-289).  batch['c_v_feats'] holds the
+    frame features; masked frames are zeroed and get the mask embedding (row 1) added here; the
+    per-subtitle stream gets its own mask embedding through batch['f_v_masks']."""
+    cm = batch["c_v_masks"]
+    b = dict(batch)
+    b["c_v_feats"] = (batch["c_v_feats"].masked_fill(cm.unsqueeze(-1), 0)
+                      + F.embedding(cm.long(), P["v_encoder.mask_embedding.weight"], padding_idx=0))  # model.py:133
+    out = forward_repr(b, P, cfg)
+    pred = feat_regress(out[cm], P)
+    if loss == "regression":
+        return F.mse_loss(pred, batch["feat_targets"], reduction="none")
+    neg = feat_regress(out[~cm], P)
+    logits = torch.cat([pred @ batch["feat_targets"].t(), pred @ neg.t()], 1)
+    return F.cross_entropy(logits / nce_temp, torch.arange(pred.shape[0]), reduction="none")
+
+
+def fom_logits(batch, P, cfg):
+    """HierarchicalVlModel.forward_fom (model.py:306-336): frames re-ordered by scatter, temporal
+    encoder, MLPLayer (layers.py:48-61: Linear -> gelu -> LN(1e-5) -> Linear)."""
+    pre = forward_repr(batch, P, cfg, encode_clip=False)
+    idx = batch["shuffled_orders"].unsqueeze(-1).expand_as(pre)
+    shuf = torch.zeros_like(pre).scatter(1, idx, pre)
+    enc = c_encoder(shuf, batch["c_attn_masks"], P, cfg)
+    x = enc.reshape(-1, enc.shape[-1])
+    pf = "v_encoder.fom_output"
+    h = layer_norm(gelu_erf(linear(x, P, pf + ".linear_1")), P, pf + ".LayerNorm", 1e-5)
+    return linear(h, P, pf + ".linear_2")
+
+
+def fom_loss(batch, P, cfg):
+    return F.cross_entropy(fom_logits(batch, P, cfg), batch["targets"].reshape(-1), ignore_index=-1)
 
 
 # --------------------------------------------------------------------------- #

@@ -77,3 +77,63 @@ def test_train_losses_grads_and_adamw(tiny, golden_dir):
     for k, v in outs.items():
         if k.startswith("after2."):
             torch.testing.assert_close(P[k[7:]].detach(), v, rtol=1e-5, atol=1e-6)
+
+
+# ---- pre-training heads (BASELINE.json configs[3]) pinned by tests/golden/case_pretrain.npz --------
+def _task_batches(batch):
+    vb = {k: v for k, v in batch.items()}
+    mlm = {"input_ids": vb["f_sub_input_ids"], "position_ids": vb["f_sub_pos_ids"], "v_feat": vb["f_v_feats"],
+           "f_pos_ids": vb["f_v_pos_ids"], "attn_masks": vb["f_attn_masks"], "gather_index": vb["f_gather_index"],
+           "txt_mask_tgt": vb["txt_mask_tgt"], "txt_labels": vb["txt_labels"]}
+    mfm = dict(vb)
+    mfm["f_v_feats"] = vb["f_v_feats"].masked_fill(vb["f_v_masks"].unsqueeze(-1), 0)
+    fom = dict(vb)
+    fom["targets"] = vb["fom_targets"]
+    for k in ("f_v_masks", "c_v_masks"):
+        fom.pop(k)
+    return mlm, mfm, fom
+
+
+def _leaf_params(P0):
+    return {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pad")) for k, v in P0.items()}
+
+
+def _check_grads(P, outs, task):
+    tied = ("v_encoder.f_encoder.embeddings.word_embeddings.weight", "v_encoder.f_encoder.lm_head.decoder.weight")
+    n = 0
+    for k, g in outs.items():
+        if not k.startswith("grad.%s." % task):
+            continue
+        name = k[len("grad.%s." % task):]
+        got = P[name].grad
+        if name == tied[0] and P[tied[1]].grad is not None:        # one tied parameter in the reference
+            got = got + P[tied[1]].grad
+        torch.testing.assert_close(got, g, rtol=1e-4, atol=1e-6)
+        n += 1
+    assert n >= 5
+
+
+def test_pretrain_heads_match_reference(tiny, golden_dir):
+    P0, cfg = tiny
+    batch, outs = O.load_npz_case(os.path.join(golden_dir, "case_pretrain.npz"))
+    mlm, mfm, fom = _task_batches(batch)
+    P = _leaf_params(P0)
+    sc = O.mlm_scores(mlm, P, cfg)
+    torch.testing.assert_close(sc.detach(), outs["mlm.scores"], **TOL)
+    loss = O.mlm_loss(mlm, P, cfg)
+    torch.testing.assert_close(loss.detach(), outs["mlm.loss"], **TOL)
+    loss.mean().backward()
+    _check_grads(P, outs, "mlm")
+    for task, kind in (("mfm-nce", "nce"), ("mffr", "regression")):
+        P = _leaf_params(P0)
+        loss = O.mfm_loss(mfm, P, cfg, loss=kind)
+        torch.testing.assert_close(loss.detach(), outs["mfm.%s.loss" % task], rtol=1e-5, atol=1e-5)
+        loss.mean().backward()
+        _check_grads(P, outs, task)
+    P = _leaf_params(P0)
+    logits = O.fom_logits(fom, P, cfg)
+    torch.testing.assert_close(logits.detach(), outs["fom.logits"], **TOL)
+    loss = O.fom_loss(fom, P, cfg)
+    torch.testing.assert_close(loss.detach(), outs["fom.loss"], **TOL)
+    loss.backward()
+    _check_grads(P, outs, "fom")

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhero_hip.so")
+LIB_PATH = os.environ.get("HERO_HIP_LIB") or os.path.join(_HERE, "libhero_hip.so")   # HERO_HIP_LIB: alternative build (A/B runs)
 
 F32, BF16 = 0, 1
 LAYOUT_K, LAYOUT_O = 0, 1

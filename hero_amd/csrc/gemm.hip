@@ -285,8 +285,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   constexpr int PASSES = BM / PR;
   constexpr int C4 = BN / 4;                        // float4 per row
   constexpr int ITERS = PR * C4 / NT;
+  // this thread's column group is the same in every iteration (NT is a multiple of C4)
+  const int c4 = (threadIdx.x % C4) * 4;
+  const int gn = n0 + c4;
+  const bool col_ok = gn < g.N;
+  const int gnc = min(gn, g.N - 4);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (use_bias) bias4 = *reinterpret_cast<const float4*>(e.bias + gnc);
+  const bool ld_aux = act == HERO_ACT_GELU_BWD || act == HERO_ACT_RELU_BWD;
+  const bool ld_c = out_f32 && e.beta != 0.f;
+  constexpr int RSTEP = NT / C4;                 // rows covered per iteration
+  // The specialised bf16 epilogues fetch the residual / saved pre-activation of the WHOLE pass up
+  // front (raw 8-byte loads, issued before the accumulators are staged, so their HBM latency hides
+  // behind the staging and its barrier); batches of 4 left ~4 exposed round trips per tile.
+  constexpr bool PRE = !GEN && sizeof(T) == 2;
+  constexpr int UN = PRE ? ITERS : 4;
 #pragma unroll 1
   for (int pass = 0; pass < PASSES; ++pass) {
+    uint2 pre_r[PRE ? ITERS : 1], pre_u[PRE ? ITERS : 1];
+    if constexpr (PRE) {
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) {
+        const int gm = m0 + pass * PR + threadIdx.x / C4 + u * RSTEP;
+        const size_t off = (size_t)min(gm, g.M - 1) * g.ldc + gnc;
+        if (R) pre_r[u] = *reinterpret_cast<const uint2*>(R + off);
+        if (ld_aux) pre_u[u] = *reinterpret_cast<const uint2*>(X + off);
+      }
+    }
     if (pass) __syncthreads();
     if (arow0 / PR == pass) {
       const int rbase = arow0 - pass * PR;
@@ -303,17 +328,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         }
     }
     __syncthreads();
-    // this thread's column group is the same in every iteration (NT is a multiple of C4)
-    const int c4 = (threadIdx.x % C4) * 4;
-    const int gn = n0 + c4;
-    const bool col_ok = gn < g.N;
-    const int gnc = min(gn, g.N - 4);
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (use_bias) bias4 = *reinterpret_cast<const float4*>(e.bias + gnc);
-    const bool ld_aux = act == HERO_ACT_GELU_BWD || act == HERO_ACT_RELU_BWD;
-    const bool ld_c = out_f32 && e.beta != 0.f;
-    constexpr int RSTEP = NT / C4;                 // rows covered per iteration
-    constexpr int UN = 4;
 #pragma unroll 1
     for (int it0 = 0; it0 < ITERS; it0 += UN) {
       size_t off[UN];
@@ -325,8 +339,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         const int gm = m0 + pass * PR + row;
         ok[u] = col_ok && gm < g.M;
         off[u] = (size_t)min(gm, g.M - 1) * g.ldc + gnc;
-        if (R) rr[u] = V4<T>::ld(R + off[u]);
-        if (ld_aux) uu[u] = V4<T>::ld(X + off[u]);
+        if constexpr (PRE) {
+          if (R) rr[u] = make_float4(__uint_as_float(pre_r[u].x << 16), __uint_as_float(pre_r[u].x & 0xffff0000u),
+                                     __uint_as_float(pre_r[u].y << 16), __uint_as_float(pre_r[u].y & 0xffff0000u));
+          if (ld_aux) uu[u] = make_float4(__uint_as_float(pre_u[u].x << 16), __uint_as_float(pre_u[u].x & 0xffff0000u),
+                                          __uint_as_float(pre_u[u].y << 16), __uint_as_float(pre_u[u].y & 0xffff0000u));
+        } else {
+          if (R) rr[u] = V4<T>::ld(R + off[u]);
+          if (ld_aux) uu[u] = V4<T>::ld(X + off[u]);
+        }
         if (ld_c) cc[u] = *reinterpret_cast<const float4*>(static_cast<const float*>(g.C) + off[u]);
       }
 #pragma unroll

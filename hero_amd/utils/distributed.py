@@ -262,7 +262,13 @@ def _host_group():
     pg = dist.distributed_c10d._get_default_group()
     if _HOST_GROUP[0] is not pg:
         _HOST_GROUP[0] = pg
-        _HOST_GROUP[1] = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        if dist.get_backend() == "gloo":
+            _HOST_GROUP[1] = None
+        else:
+            try:
+                _HOST_GROUP[1] = dist.new_group(backend="gloo")
+            except Exception:                     # no usable host interface: sizes travel through RCCL
+                _HOST_GROUP[1] = "device"
     return _HOST_GROUP[1]
 
 
@@ -273,9 +279,11 @@ def gather_negatives(query, context, context_mask, return_own=False):
     n = world_size()
     # the sizes are host values (tensor shapes): exchange them on the host (gloo side group) so the
     # forward pass has no device synchronisation in it
-    meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]], dtype=torch.int64)
+    hg = _host_group()
+    meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]], dtype=torch.int64,
+                        device=query.device if hg == "device" else "cpu")
     metas = [torch.empty_like(meta) for _ in range(n)]
-    dist.all_gather(metas, meta, group=_host_group())
+    dist.all_gather(metas, meta, group=None if hg == "device" else hg)
     metas = torch.stack(metas).tolist()
     nq = [m[0] for m in metas]
     nv = [m[1] for m in metas]

@@ -38,13 +38,15 @@ def qkv_groups(model):
 
 
 class TrainStep:
-    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False):
+    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=True):
+        """static_usage: every step touches the same parameters (single-task fine-tuning) - lets the
+        gradient buckets that also hold never-used parameters overlap with backward too."""
         self.model = model
         self.opts = SimpleNamespace(**{**TVR_OPTS, **(opts or {})})
         self.task = task
         self.optimizer = build_optimizer(model, self.opts)
         self.arena = D.GradArena(list(model.parameters()), bucket_bytes=bucket_bytes,
-                                 groups=qkv_groups(model))
+                                 groups=qkv_groups(model), static_usage=static_usage)
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152

@@ -93,7 +93,8 @@ class GradArena(HF.GradSink):
     optimiser or call `scale_()`.
     """
 
-    def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True, groups=()):
+    def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True, groups=(),
+                 static_usage=False):
         """groups: tuples of parameters whose gradients must be CONTIGUOUS in the arena, in the given
         order (e.g. an attention block's query/key/value weights: the backward then writes
         d[Wq;Wk;Wv] with one GEMM instead of three, see hero_amd.functional._qkv_bwd)."""
@@ -134,6 +135,12 @@ class GradArena(HF.GradSink):
             p.grad = self.flat[s:e].view_as(p)
         self.sync = True
         self.overlap = overlap
+        # static_usage: the caller guarantees that every optimiser step touches the same parameters
+        # (one task, fixed graph).  Buckets then wait only for the parameters that received a gradient
+        # in the previous step, so a bucket that also holds never-used parameters (pooler, lm_head,
+        # ...) is still all-reduced as soon as its used gradients are final instead of in finish().
+        self.static_usage = static_usage
+        self._expect = None
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._final = set()
@@ -192,6 +199,9 @@ class GradArena(HF.GradSink):
         self._final.add(p)
         if not (self.sync and self.overlap) or world_size() == 1:
             return
+        if self._expect is not None and p not in self._expect:
+            raise RuntimeError("GradArena(static_usage=True): a parameter of shape %s received a gradient "
+                               "in this step but not in the previous one" % (tuple(p.shape),))
         b = self.bucket_of[p]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -205,8 +215,11 @@ class GradArena(HF.GradSink):
         self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def set_sync(self, flag):
-        """False on gradient-accumulation micro-steps that do not end in an optimiser step."""
+        """Call at the start of every micro-step; False on gradient-accumulation micro-steps that do
+        not end in an optimiser step."""
         self.sync = flag
+        self._final.clear()          # finality is per backward pass (accumulation adds to the same slots)
+        self._uses.clear()
 
     def finish(self):
         """Issue all-reduces for buckets the hooks did not complete, then wait for everything."""
@@ -216,7 +229,14 @@ class GradArena(HF.GradSink):
             for h in self._handles:
                 h.wait()
         self._handles = []
-        self._pending = [b[2] for b in self.buckets]
+        if self.static_usage and self.touched:
+            self._expect = frozenset(self.touched)
+        if self._expect is not None:
+            self._pending = [0] * len(self.buckets)
+            for p in self._expect:
+                self._pending[self.bucket_of[p]] += 1
+        else:
+            self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._final.clear()
         self._uses.clear()

@@ -60,7 +60,7 @@ def _arena(rank, world):
     w1 = torch.nn.Parameter(torch.randn(6, 6))
     w2 = torch.nn.Parameter(torch.randn(6, 6))
     w3 = torch.nn.Parameter(torch.randn(5))           # never used -> stays zero, not 'touched'
-    arena = D.GradArena([w1, w2, w3], bucket_bytes=64, overlap=True)
+    arena = D.GradArena([w1, w2, w3], bucket_bytes=64, overlap=True, static_usage=True)
 
     class SinkMul(torch.autograd.Function):          # y = x @ w2, grad of w2 written via the sink
         @staticmethod
@@ -84,21 +84,33 @@ def _arena(rank, world):
         ((x @ a) @ b + (x @ b)).sum().backward()
         return a.grad, b.grad
 
-    out = []
-    for micro in range(2):                            # gradient accumulation: sync only on the 2nd
-        arena.set_sync(micro == 1)
-        g = torch.Generator().manual_seed(10 + rank)
-        x = torch.randn(4, 6, generator=g)
-        h = x @ w1
-        y = SinkMul.apply(h, w2) + SinkMul.apply(x, w2)
-        y.sum().backward()
+    def cycle():
+        for micro in range(2):                        # gradient accumulation: sync only on the 2nd
+            arena.set_sync(micro == 1)
+            g = torch.Generator().manual_seed(10 + rank)
+            x = torch.randn(4, 6, generator=g)
+            h = x @ w1
+            y = SinkMul.apply(h, w2) + SinkMul.apply(x, w2)
+            y.sum().backward()
+        return sum(arena._launched)                   # buckets all-reduced from the hooks, before finish()
+
+    # buckets: [w3, w2] and [w1].  First cycle: w1's bucket overlaps (the unsynchronised first
+    # micro-step must not leave it marked final); the other waits for the never-used w3 until finish().
+    overlapped = cycle()
     arena.finish()
-    arena.scale_(1.0 / world)
+    arena.zero()
+    # static_usage: from the second optimiser step on, only parameters that got a gradient last step
+    # are waited for -> both buckets overlap
+    overlapped2 = cycle()
+    arena.finish()
+    arena.scale_(0.5)                                 # (two cycles' worth of identical gradients / 2 ... see below)
+    arena.scale_(2.0 / world)                         # undo the 0.5 above, then average over ranks
     e1 = sum(local_grads(r)[0] for r in range(world)) * 2 / world
     e2 = sum(local_grads(r)[1] for r in range(world)) * 2 / world
     ok = torch.allclose(w1.grad, e1, atol=1e-5) and torch.allclose(w2.grad, e2, atol=1e-5)
     ok = ok and w1.grad.data_ptr() == arena.flat.data_ptr() + arena.slices[w1][0] * 4
     ok = ok and arena.touched == {w1, w2} and float(w3.grad.abs().sum()) == 0.0
+    ok = ok and len(arena.buckets) == 2 and overlapped == 1 and overlapped2 == 2
     arena.zero()
     ok = ok and float(arena.flat.abs().sum()) == 0.0 and not arena.touched
     HF.set_grad_sink(None)

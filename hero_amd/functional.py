@@ -214,10 +214,12 @@ def set_grad_sink(sink):
 
 
 def _use(*params):
-    if torch.is_grad_enabled():
-        for p in params:
-            if p is not None and p.requires_grad:
-                SINK.use(p)
+    """Count one forward use of each parameter (called from inside autograd.Function.forward, where
+    grad mode is always off - so no is_grad_enabled() test here; the sink resets its counts at the
+    start of every micro-step)."""
+    for p in params:
+        if p is not None and p.requires_grad:
+            SINK.use(p)
 
 
 def _is_param(t):

@@ -44,26 +44,39 @@ def main():
     assert torch.equal(both[0], both[1]), "parameter broadcast failed"
 
     batch = make_batch("D1", vfeat_dim=96, vocab=160, seed=1 + rank, device=dev)
-    # (2) local gradients of two accumulated micro-steps WITHOUT synchronisation
-    trainer.arena.zero()
-    for _ in range(2):
+    errs = []
+    for fuse in (True, False):       # False: the cross-modal layers run twice per forward (two uses per parameter)
+        model.fuse_query_pass = fuse
+        # (2) local gradients of two accumulated micro-steps WITHOUT synchronisation
+        trainer.arena.zero()
+        for _ in range(2):
+            trainer.arena.set_sync(False)
+            trainer._fwd_bwd(batch)
+            trainer.arena.finish()
+        local = trainer.arena.flat.clone()
+        gl = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gl, local)
+        want_sum = gl[0] + gl[1]
+        # (3) the same two micro-steps through the production path: buckets all-reduced from the hooks
+        trainer.arena.zero()
         trainer.arena.set_sync(False)
         trainer._fwd_bwd(batch)
+        trainer.arena.set_sync(True)
+        trainer._fwd_bwd(batch)
         trainer.arena.finish()
-    local = trainer.arena.flat.clone()
-    gl = [torch.zeros_like(local) for _ in range(world)]
-    dist.all_gather(gl, local)
-    want_sum = gl[0] + gl[1]
-    # (3) the same two micro-steps through the production path: buckets all-reduced from the hooks
-    trainer.arena.zero()
-    trainer.arena.set_sync(False)
-    trainer._fwd_bwd(batch)
-    trainer.arena.set_sync(True)
-    trainer._fwd_bwd(batch)
-    trainer.arena.finish()
-    got = trainer.arena.flat.clone()
-    err = (got - want_sum).abs().max().item() / max(want_sum.abs().max().item(), 1e-12)
-    assert err < 1e-5, "bucketed all-reduce != sum of local gradients (rel %g)" % err
+        got = trainer.arena.flat.clone()
+        err = (got - want_sum).abs().max().item() / max(want_sum.abs().max().item(), 1e-12)
+        if err >= 1e-5:
+            bad = []
+            for n_, p_ in named.items():
+                s_, e_ = trainer.arena.slices[p_]
+                d_ = (got[s_:e_] - want_sum[s_:e_]).abs().max().item()
+                if d_ > 1e-6 * max(want_sum.abs().max().item(), 1e-12):
+                    bad.append((round(d_ / max(want_sum[s_:e_].abs().max().item(), 1e-12), 4), n_, trainer.arena.bucket_of[p_]))
+            print("RANK", rank, "mismatching parameters:", sorted(bad, reverse=True)[:12], flush=True)
+        assert err < 1e-5, "bucketed all-reduce != sum of local gradients (rel %g)" % err
+        errs.append(err)
+    err = max(errs)
     nb = len(trainer.arena.buckets)
     # (4) full optimiser steps keep the replicas identical
     trainer.arena.zero()

@@ -1,4 +1,7 @@
-// Masked multi-head self-attention, head size 64, forward and backward (gfx950).
+// Masked multi-head self-attention, head size 64, forward and backward (gfx950): the fp32-VALU
+// kernels.  They serve the f32 parity mode at every length and bf16 for 64 < L <= 256; bf16 with
+// L <= 64 (every sequence of the TVR step) is dispatched to the matrix-core kernels of
+// attention_mfma.hip, which issue ~10x fewer wave instructions per head.
 //
 // HERO's sequences are short (a subtitle's frames+tokens: 10-40; a clip's frames: <= 100; the
 // long-video stress case: 256), so attention is < 1 % of the FLOPs of a layer and is bound by

@@ -58,7 +58,7 @@ class Attn(C.Structure):
     _fields_ = [("qkv", C.c_void_p), ("mask", C.c_void_p), ("ctx", C.c_void_p),
                 ("probs", C.c_void_p), ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("S", C.c_int), ("L", C.c_int), ("H", C.c_int), ("scale", C.c_float),
-                ("dtype", C.c_int), ("dropout", Dropout)]
+                ("dtype", C.c_int), ("dropout", Dropout), ("seq_off", C.c_void_p)]
 
 
 class AdamW(C.Structure):

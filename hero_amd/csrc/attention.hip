@@ -322,8 +322,14 @@ template <typename T, int LPK>
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DPL = DH / LPK;
-  const int L = a.L, H = a.H, D = H * DH;
+  const int H = a.H, D = H * DH;
   const int s = blockIdx.x / H, h = blockIdx.x % H;
+  // packed (variable-length) batches: rows [seq_off[s], seq_off[s+1]); a.L is the maximum length and
+  // stays the stride of the probabilities and of the dropout indices
+  const int Lm = a.L, Lpm = (Lm + 3) & ~3;
+  const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
+  const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
+  if (L <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Lp = (L + 3) & ~3;
   float* Qs = reinterpret_cast<float*>(smem);
@@ -332,18 +338,18 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(HeroAttn a) {
   float* Ms = Vs + L * DH;
   float* Ps = Ms + Lp + wave * Lp;
 
-  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D + h * DH;
+  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)row0 * 3 * D + h * DH;
   stage_f32<T>(qkv, 3 * D, L, Qs, DH);
   stage_f32<T>(qkv + D, 3 * D, L, Ks, KS);
   stage_f32<T>(qkv + 2 * D, 3 * D, L, Vs, DH);
-  for (int j = threadIdx.x; j < L; j += 256) Ms[j] = a.mask ? a.mask[(size_t)s * L + j] : 0.f;
+  for (int j = threadIdx.x; j < L; j += 256) Ms[j] = a.mask ? a.mask[(size_t)s * Lm + j] : 0.f;
   __syncthreads();
 
   DropCtx drop(a.dropout);
   const int g = lane / LPK, p = lane % LPK;
   const bool valid = g < L;
-  T* ctx = static_cast<T*>(a.ctx) + (size_t)s * L * D + h * DH;
-  float* probs = a.probs ? a.probs + ((size_t)(s * H + h) * L) * L : nullptr;
+  T* ctx = static_cast<T*>(a.ctx) + (size_t)row0 * D + h * DH;
+  float* probs = a.probs ? a.probs + ((size_t)(s * H + h) * Lm) * Lm : nullptr;
   const float mj = valid ? Ms[g] : 0.f;
   const float* krow = Ks + (valid ? g : 0) * KS + p * DPL;
 
@@ -357,8 +363,8 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(HeroAttn a) {
     const float sum = wave_sum(p == 0 ? e : 0.f);
     float pr = e * (1.f / sum);
     if (valid && p == 0) {
-      if (probs) probs[(size_t)i * L + g] = pr;
-      if (drop.on()) pr *= drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + g);
+      if (probs) probs[(size_t)i * Lm + g] = pr;
+      if (drop.on()) pr *= drop.mask1(((uint64_t)(s * H + h) * Lm + i) * (uint64_t)Lpm + g);
       Ps[g] = pr;
     }
     wave_lds_sync();
@@ -381,8 +387,14 @@ template <typename T, int LPK>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DPL = DH / LPK;
-  const int L = a.L, H = a.H, D = H * DH;
+  const int H = a.H, D = H * DH;
   const int s = blockIdx.x / H, h = blockIdx.x % H;
+  // packed (variable-length) batches: rows [seq_off[s], seq_off[s+1]); a.L is the maximum length and
+  // stays the stride of the probabilities and of the dropout indices
+  const int Lm = a.L, Lpm = (Lm + 3) & ~3;
+  const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
+  const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
+  if (L <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Lp = (L + 3) & ~3;
   float* Qs = reinterpret_cast<float*>(smem);   // [L][64]
@@ -392,17 +404,17 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(HeroAttn a) {
   float* dS = Vs + L * KS;                       // [L][Lp]  (scaled)
   float* Pd = dS + L * Lp;                       // [L][Lp]  P on entry, dropped P afterwards
 
-  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D + h * DH;
-  const T* dctx = static_cast<const T*>(a.dctx) + (size_t)s * L * D + h * DH;
+  const T* qkv = static_cast<const T*>(a.qkv) + (size_t)row0 * 3 * D + h * DH;
+  const T* dctx = static_cast<const T*>(a.dctx) + (size_t)row0 * D + h * DH;
   stage_f32<T>(qkv, 3 * D, L, Qs, DH);
   stage_f32<T>(qkv + D, 3 * D, L, Ks, KS);
   stage_f32<T>(qkv + 2 * D, 3 * D, L, Vs, KS);
   stage_f32<T>(dctx, D, L, Os, DH);
   {
-    const float* src = a.probs + ((size_t)(s * H + h) * L) * L;
+    const float* src = a.probs + ((size_t)(s * H + h) * Lm) * Lm;
     for (int q = threadIdx.x; q < L * L; q += 256) {
       const int i = q / L, j = q - i * L;
-      Pd[i * Lp + j] = src[q];
+      Pd[i * Lp + j] = src[(size_t)i * Lm + j];
     }
     for (int q = threadIdx.x; q < L * (Lp - L); q += 256) {   // zero the row padding read by the quad phase
       const int i = q / (Lp - L), j = L + q % (Lp - L);
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(HeroAttn a) {
   DropCtx drop(a.dropout);
   const int g = lane / LPK, p = lane % LPK;
   const bool valid = g < L;
-  T* dqkv = static_cast<T*>(a.dqkv) + (size_t)s * L * 3 * D + h * DH;
+  T* dqkv = static_cast<T*>(a.dqkv) + (size_t)row0 * 3 * D + h * DH;
   const float* vrow = Vs + (valid ? g : 0) * KS + p * DPL;
 
   // ---- phase A: one wave per query row -> dS row, dropped-P row (LDS), dQ row (HBM)
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(HeroAttn a) {
     if (valid) {
       pr = Pdr[g];
       if (drop.on()) {
-        const float m = drop.mask1(((uint64_t)(s * H + h) * L + i) * (uint64_t)Lp + g);
+        const float m = drop.mask1(((uint64_t)(s * H + h) * Lm + i) * (uint64_t)Lpm + g);
         dp *= m;
         if (p == 0) Pdr[g] = pr * m;
       }
@@ -573,6 +585,7 @@ static int check_attn(const HeroAttn* a, bool bwd) {
   HERO_REQUIRE(a && a->qkv, "hero_attention: null qkv");
   HERO_REQUIRE(a->S >= 0 && a->L > 0 && a->H > 0, "hero_attention: bad dims S=%d L=%d H=%d", a->S, a->L, a->H);
   HERO_REQUIRE(a->dtype == HERO_F32 || a->dtype == HERO_BF16, "hero_attention: bad dtype %d", a->dtype);
+  HERO_REQUIRE(!a->seq_off || a->L <= 64, "hero_attention: packed batches (seq_off) need L <= 64, got %d", a->L);
   if (bwd) HERO_REQUIRE(a->probs && a->dctx && a->dqkv, "hero_attention_bwd: probs/dctx/dqkv required");
   else HERO_REQUIRE(a->ctx, "hero_attention_fwd: ctx required");
   return HERO_OK;

@@ -126,9 +126,14 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
   const int pair = blockIdx.x * WPB + wave;
   if (pair >= a.S * a.H) return;                       // wave-uniform; no workgroup barriers below
-  const int s = pair / a.H, h = pair - s * a.H, L = a.L, D = a.H * 64, ld = 3 * D, Lp = (L + 3) & ~3;
+  const int s = pair / a.H, h = pair - s * a.H, D = a.H * 64, ld = 3 * D;
+  // packed batches: rows [seq_off[s], seq_off[s+1]); a.L (the maximum) stays the stride of probs / dropout indices
+  const int Lm = a.L, Lp = (Lm + 3) & ~3;
+  const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
+  const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
+  if (L <= 0) return;
   bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (32 * NB * RS);
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)s * L * ld + h * 64;
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
   const bf16_t* kp = qp + D;
   const bf16_t* vp = qp + 2 * D;
 
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 32 * jt + acc_row(r, half);
-      mk[jt][r] = a.mask ? a.mask[(size_t)s * L + min(j, L - 1)] : 0.f;
+      mk[jt][r] = a.mask ? a.mask[(size_t)s * Lm + min(j, L - 1)] : 0.f;
     }
   // V^T fragments: k-slot e of step ks <-> key 32 jt + 16 ks + 4 half + (e & 3) + 8 (e >> 2), i.e. the
   // keys this lane holds in accumulator registers 8 ks .. 8 ks + 7
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
       }
     sum += xhalf(sum);
     const float inv = 1.f / sum;
-    float* prow = a.probs ? a.probs + ((size_t)(s * a.H + h) * L + min(i, L - 1)) * L : nullptr;
-    const uint64_t drow = ((uint64_t)(s * a.H + h) * L + i) * (uint64_t)Lp;
+    float* prow = a.probs ? a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm : nullptr;
+    const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
 #pragma unroll
     for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
           cx[dt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][jt][ks], pack8(&p[jt][8 * ks]), cx[dt][it], 0, 0, 0);
     }
   }
-  store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)s * L * D + h * 64, D, L, cx, lane);
+  store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, cx, lane);
 }
 
 template <int NB, int WPB>
@@ -247,16 +252,20 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
   const int pair = blockIdx.x * WPB + wave;
   if (pair >= a.S * a.H) return;
-  const int s = pair / a.H, h = pair - s * a.H, L = a.L, D = a.H * 64, ld = 3 * D, Lp = (L + 3) & ~3;
+  const int s = pair / a.H, h = pair - s * a.H, D = a.H * 64, ld = 3 * D;
+  const int Lm = a.L, Lp = (Lm + 3) & ~3;
+  const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
+  const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
+  if (L <= 0) return;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + wave * WAVE_BYTES);
   bf16_t* Qs = Ks + R * RS;
   bf16_t* Os = Qs + R * RS;
   bf16_t* Pl = Os + R * RS;                              // dropped probabilities [i][j]
   bf16_t* Sl = Pl + R * PS;                              // dS [i][j]
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)s * L * ld + h * 64;
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
   const bf16_t* kp = qp + D;
   const bf16_t* vp = qp + 2 * D;
-  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)s * L * D + h * 64;
+  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)row0 * D + h * 64;
 
   stage_tile<NB>(kp, ld, L, Ks, lane);
   stage_tile<NB>(qp, ld, L, Qs, lane);
@@ -298,13 +307,13 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
       }
 
   DropCtx drop(a.dropout);
-  bf16_t* dq = static_cast<bf16_t*>(a.dqkv) + (size_t)s * L * ld + h * 64;
+  bf16_t* dq = static_cast<bf16_t*>(a.dqkv) + (size_t)row0 * ld + h * 64;
   f32x16_t gq[2][NB];
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
     const int i = 32 * it + l31;
-    const float* prow = a.probs + ((size_t)(s * a.H + h) * L + min(i, L - 1)) * L;
-    const uint64_t drow = ((uint64_t)(s * a.H + h) * L + i) * (uint64_t)Lp;
+    const float* prow = a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm;
+    const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
     float pr[NB][16], ds[NB][16];
 #pragma unroll
     for (int jt = 0; jt < NB; ++jt)

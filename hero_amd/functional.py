@@ -405,20 +405,22 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
     return dx, (dxd if dxd is not None else dx), dg, db
 
 
-def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None):
+def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None, seq_off=None):
+    """seq_off (int32 [S+1]): packed batch - sequence s is rows [seq_off[s], seq_off[s+1]) of qkv,
+    Lq is the maximum length (<= 64)."""
     D = H * 64
-    ctx = out if out is not None else torch.empty((S * Lq, D), dtype=qkv.dtype, device=qkv.device)
+    ctx = out if out is not None else torch.empty((qkv.shape[0], D), dtype=qkv.dtype, device=qkv.device)
     probs = torch.empty((S, H, Lq, Lq), dtype=torch.float32, device=qkv.device) if want_probs else None
     a = L.Attn(L.ptr(qkv), L.ptr(mask_add), L.ptr(ctx), L.ptr(probs), None, None, S, Lq, H,
-               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop))
+               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off))
     L.check(L.lib().hero_attention_fwd(C.byref(a), L.stream()))
     return ctx, probs
 
 
-def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None, out=None):
+def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None, out=None, seq_off=None):
     dqkv = out if out is not None else torch.empty_like(qkv)
     a = L.Attn(L.ptr(qkv), None, None, L.ptr(probs), L.ptr(dctx), L.ptr(dqkv), S, Lq, H,
-               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop))
+               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off))
     L.check(L.lib().hero_attention_bwd(C.byref(a), L.stream()))
     return dqkv
 
@@ -622,6 +624,24 @@ class GatherRowsFn(torch.autograd.Function):
         return da, db, None
 
 
+class PermuteRowsFn(torch.autograd.Function):
+    """out[r] = a[idx[r]] (idx >= 0) | 0 (idx == -1) for an INJECTIVE idx; `inv` is the reverse map
+    (source row -> output row or -1), so the backward is a gather too (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, a, idx, inv):
+        a2 = _as2d(a)
+        ctx.save_for_backward(inv)
+        ctx.ashape = a.shape
+        return k_gather_rows(a2, None, idx, idx.numel(), a2.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inv,) = ctx.saved_tensors
+        dy2 = _as2d(dy)
+        return k_gather_rows(dy2, None, inv, inv.numel(), dy2.shape[1]).view(ctx.ashape), None, None
+
+
 class CsrGatherSumFn(torch.autograd.Function):
     """out[r] = sum_e src[entries[e]], e in [offsets[r], offsets[r+1]); inverse = src row -> out row
     (each source row feeds at most one output row: collect_frame_outputs, model/model.py:156-187)."""
@@ -745,7 +765,13 @@ class AttnBlockFn(torch.autograd.Function):
         ctxt = torch.empty((x2.shape[0], D), dtype=x2.dtype, device=x2.device)
         probs = []
         r0 = 0
-        for (S, Lq), m, dr in zip(segs, masks, drops_attn):      # each group writes its row slice
+        for seg, m, dr in zip(segs, masks, drops_attn):          # each group writes its row slice
+            if len(seg) == 4:                                    # ("packed", S, Lmax, seq_off): all rows
+                _, S, Lq, off = seg
+                _, p = k_attn_fwd(qkv, None, S, Lq, H, drop=dr, out=ctxt, seq_off=off)
+                probs.append(p)
+                continue
+            S, Lq = seg
             _, p = k_attn_fwd(qkv[r0:r0 + S * Lq], m, S, Lq, H, drop=dr, out=ctxt[r0:r0 + S * Lq])
             probs.append(p)
             r0 += S * Lq
@@ -776,7 +802,12 @@ class AttnBlockFn(torch.autograd.Function):
         dctx = k_dgrad_t(dy1d, Wo_t)
         dqkv = torch.empty_like(qkv)
         r0 = 0
-        for (S, Lq), p, dr in zip(segs, probs, drops_attn):
+        for seg, p, dr in zip(segs, probs, drops_attn):
+            if len(seg) == 4:
+                _, S, Lq, off = seg
+                k_attn_bwd(qkv, p, dctx, S, Lq, H, drop=dr, out=dqkv, seq_off=off)
+                continue
+            S, Lq = seg
             k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr,
                        out=dqkv[r0:r0 + S * Lq])
             r0 += S * Lq

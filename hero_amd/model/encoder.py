@@ -94,6 +94,7 @@ class CrossModalTrm(RobertaPreTrainedModel):
     def __init__(self, config, vfeat_dim, max_img_seq_len):
         super().__init__(config)
         self.encoder = BertEncoder(config)
+        self.encoder.pack_ragged = True      # outputs at masked positions are never read (layers.py)
         self.embeddings = SubEmbeddings(config)
         self.img_embeddings = ImageEmbeddings(config, vfeat_dim, max_img_seq_len)
         self.pooler = BertPooler(config)

@@ -223,6 +223,9 @@ class BertEncoder(nn.Module):
         self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None):
+        if (self.pack_ragged and BertEncoder.allow_packing and attention_mask is not None and hidden_states.is_cuda
+                and attention_mask.dim() == 2 and attention_mask.dtype != torch.float32):
+            return (self.forward_multi([hidden_states], [attention_mask])[0],)
         x = HF.cast(hidden_states, HF.compute_dtype())
         S, Lq, _ = x.shape
         m = HF.as_mask_add(attention_mask, S, Lq)        # (1-m)*-10000, model/layers.py:299-302
@@ -231,17 +234,76 @@ class BertEncoder(nn.Module):
             x = layer(x, m4, None)[0]
         return (x,)
 
+    # Drop masked positions before the layer stack when that saves > 10 % of the rows.  Only valid where
+    # nothing downstream reads the outputs at masked positions: true for the cross-modal encoder
+    # (CrossModalTrm turns it on), NOT for the temporal one - the start/end Conv1d of the VSM head mixes
+    # the (finite garbage) outputs at padded frames into the logits of the last valid frames
+    # (model/pretrain.py:128-166), so those rows must keep the reference's values.
+    pack_ragged = False
+    _PLANS = {}
+    allow_packing = True    # global switch (tests compare against the padded formulation)
+
+    @staticmethod
+    def _pack_plan(mask_list, lens):
+        """Row maps between the padded layout (groups stacked, row = position) and the packed one
+        (masked positions removed, sequences back to back).  None when (almost) every position is
+        valid.  One small device->host read per distinct batch; cached on the mask tensors."""
+        key = tuple((m.data_ptr(), m._version, tuple(m.shape)) for m in mask_list)
+        hit = BertEncoder._PLANS.get(key)
+        if hit is not None:
+            return hit[0]
+        dev = mask_list[0].device
+        flat = torch.cat([(m != 0).reshape(-1) for m in mask_list]).cpu()
+        total = flat.numel()
+        valid = int(flat.sum())
+        plan = None
+        counts = torch.cat([(m != 0).sum(1).reshape(-1) for m in mask_list]).cpu()
+        lmax = int(counts.max()) if counts.numel() else 0
+        if 0 < valid < 0.9 * total and lmax <= 64:
+            gather = torch.nonzero(flat, as_tuple=False).reshape(-1).to(torch.int32)
+            inverse = torch.full((total,), -1, dtype=torch.int32)
+            inverse[gather.long()] = torch.arange(valid, dtype=torch.int32)
+            off = torch.zeros(counts.numel() + 1, dtype=torch.int32)
+            off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            inv, back, r0 = [], [], 0
+            for n in lens:                                   # per group: padded -> packed and packed -> padded
+                inv.append(inverse[r0:r0 + n].contiguous().to(dev))
+                g = gather - r0
+                back.append(torch.where((g >= 0) & (g < n), g, torch.full_like(g, -1)).to(dev))
+                r0 += n
+            plan = (gather.to(dev), inverse.to(dev), inv, back, off.to(dev), int(counts.numel()), lmax)
+        if len(BertEncoder._PLANS) > 64:
+            BertEncoder._PLANS.clear()
+        BertEncoder._PLANS[key] = (plan, mask_list)          # keep the masks alive: ids stay unique
+        return plan
+
     def forward_multi(self, hidden_list, mask_list):
         """Run several independent sequence groups (tensors (S_i, L_i, D) + their (S_i, L_i) 0/1
         masks) through the SAME layer stack as one stacked row batch: GEMMs, LayerNorms and their
         backward kernels are launched once for all groups, attention once per group.  Numerically
-        identical to calling forward() per group (every other op is row-wise)."""
+        identical to calling forward() per group (every other op is row-wise).
+
+        Ragged batches (SURVEY 8d 'ragged' variant; every real TVR batch): masked positions carry no
+        information for the valid ones (their keys get exp(-1e4) = 0 weight, model/layers.py:299-302)
+        and the reference's outputs at those positions are unused garbage, so they are dropped before
+        the stack - the rows are PACKED, attention runs variable-length (hero_attention seq_off) and
+        the result is scattered back to the padded layout with zeros at the masked positions."""
         cd = HF.compute_dtype()
         xs = [HF.cast(h, cd) for h in hidden_list]
         segs = tuple((x.shape[0], x.shape[1]) for x in xs)
-        masks = tuple(HF.as_mask_add(m, s[0], s[1]) for m, s in zip(mask_list, segs))
         D = xs[0].shape[-1]
-        x = torch.cat([t.reshape(-1, D) for t in xs], 0)
+        x = torch.cat([t.reshape(-1, D) for t in xs], 0) if len(xs) > 1 else xs[0].reshape(-1, D)
+        plan = None
+        if self.pack_ragged and BertEncoder.allow_packing and all(m is not None for m in mask_list) and x.is_cuda:
+            plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs])
+        if plan is not None:
+            gather, inverse, inv, back, off, n_seq, lmax = plan
+            x = HF.PermuteRowsFn.apply(x.contiguous(), gather, inverse)
+            packed = (("packed", n_seq, lmax, off),)
+            for layer in self.layer:
+                x = layer.forward_rows(x, packed, (None,))
+            return [HF.PermuteRowsFn.apply(x, i_, b_).view(S, Lq, D) for i_, b_, (S, Lq) in zip(inv, back, segs)]
+        masks = tuple(HF.as_mask_add(m, s[0], s[1]) for m, s in zip(mask_list, segs))
         for layer in self.layer:
             x = layer.forward_rows(x, segs, masks)
         outs, r0 = [], 0

@@ -155,6 +155,9 @@ typedef struct HeroAttn {
   float scale;        /* 1/sqrt(64)                                                             */
   int dtype;
   HeroDropout dropout; /* on P; index = ((s*H+h)*L + q)*round_up(L,4) + k                       */
+  const int32_t* seq_off; /* optional [S+1] row offsets of a PACKED batch (L <= 64): sequence s is   */
+                       /* rows [seq_off[s], seq_off[s+1]) of qkv/ctx/dctx/dqkv, at most L long;   */
+                       /* probs keeps its [S, H, L, L] layout, dropout indices use L; mask NULL   */
 } HeroAttn;
 int hero_attention_fwd(const HeroAttn* a, hero_stream_t stream);
 int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream);

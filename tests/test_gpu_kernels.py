@@ -179,6 +179,34 @@ def test_attention_fwd_bwd(HF, dtype, S, L, H):
     close(dqkv, q.grad, dtype, scale=2)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lens,H", [([24, 9, 1, 17, 24], 3), ([60, 33, 5], 2), ([15, 15], 12), ([7], 1)])
+def test_attention_packed_sequences(HF, dtype, lens, H):
+    """Variable-length (packed) batches: sequence s = rows [off[s], off[s+1]) - same result as running
+    every sequence on its own, forward and backward, with and without dropout (self-consistent)."""
+    D = H * 64
+    S, Lmax, M = len(lens), max(lens), sum(lens)
+    off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32).cuda()
+    qkv = rnd(M, 3 * D, dtype=dtype, seed=1)
+    dctx = rnd(M, D, dtype=dtype, seed=2)
+    ctx, probs = HF.k_attn_fwd(qkv, None, S, Lmax, H, seq_off=off)
+    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, Lmax, H, seq_off=off)
+    r0 = 0
+    for s_, n in enumerate(lens):
+        c1, p1 = HF.k_attn_fwd(qkv[r0:r0 + n].contiguous(), None, 1, n, H)
+        d1 = HF.k_attn_bwd(qkv[r0:r0 + n].contiguous(), p1, dctx[r0:r0 + n].contiguous(), 1, n, H)
+        close(ctx[r0:r0 + n], c1, dtype)
+        torch.testing.assert_close(probs[s_, :, :n, :n], p1[0], rtol=1e-5, atol=1e-6)
+        close(dqkv[r0:r0 + n], d1, dtype, scale=2)
+        r0 += n
+    drop = HF.RNG.make(0.2, True, qkv.device)
+    cd, pd = HF.k_attn_fwd(qkv, None, S, Lmax, H, drop=drop, seq_off=off)
+    dd = HF.k_attn_bwd(qkv, pd, dctx, S, Lmax, H, drop=drop, seq_off=off)
+    lhs = (dctx.float() * cd.float()).sum()
+    rhs = (dd[:, 2 * D:].float() * qkv[:, 2 * D:].float()).sum()
+    torch.testing.assert_close(lhs, rhs, rtol=2e-2 if dtype == torch.bfloat16 else 1e-3, atol=0.5 if dtype == torch.bfloat16 else 1e-2)
+
+
 def test_attention_dropout_adjoint(HF, Lb):
     """With dropout on, forward is linear in V for a fixed mask and backward must use the SAME mask:
     <dctx, ctx(V)> == <dV, V>.  Also the keep rate is 1-p."""

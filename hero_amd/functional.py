@@ -461,6 +461,25 @@ def _as2d(x):
     return x.view(-1, x.shape[-1])
 
 
+_MEMO = {}
+
+
+def memo(tag, tensors, fn, extra=()):
+    """Cache a tensor DERIVED from batch index / mask tensors (int32 row indices, additive masks,
+    flat gather maps) on the identity + version of its sources: the same batch object is fed for
+    several micro-steps (gradient accumulation, hipGraph warm-up) and these conversions are a few
+    dozen tiny launches each time.  The sources are kept alive so their addresses stay unique."""
+    key = (tag, extra) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
+    hit = _MEMO.get(key)
+    if hit is not None:
+        return hit[0]
+    if len(_MEMO) > 512:
+        _MEMO.clear()
+    out = fn()
+    _MEMO[key] = (out, tensors)
+    return out
+
+
 def as_mask_add(mask, S, Lq):
     """Reference mask convention -> [S, L] additive fp32.  Accepts the (S,L) 0/1 mask of
     BertEncoder.forward or the extended (S,1,1,L) additive mask BertLayer receives."""
@@ -470,7 +489,10 @@ def as_mask_add(mask, S, Lq):
         if mask.shape[1] != 1 or mask.shape[2] != 1:
             raise NotImplementedError("hero_amd attention supports key masks of shape (S,1,1,L) only")
         return mask.reshape(S, Lq).to(torch.float32).contiguous()
-    return ((1.0 - mask.reshape(S, Lq).to(torch.float32)) * -10000.0).contiguous()
+    if mask.requires_grad:
+        return ((1.0 - mask.reshape(S, Lq).to(torch.float32)) * -10000.0).contiguous()
+    return memo("mask_add", (mask,), lambda: ((1.0 - mask.reshape(S, Lq).to(torch.float32)) * -10000.0).contiguous(),
+                (S, Lq))
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -7,6 +7,9 @@ from .. import functional as HF
 from .layers import LayerNorm, _drop
 
 
+_ARANGE = {}
+
+
 def _row_index(ids, rows, cols_per_row):
     """Per-output-row int32 table index from the reference's (1, L) or (S, L) id tensors."""
     if ids.dim() == 1:
@@ -16,7 +19,7 @@ def _row_index(ids, rows, cols_per_row):
     if ids.shape != (rows, cols_per_row):
         raise ValueError("index tensor of shape %s does not match (%d, %d)" %
                          (tuple(ids.shape), rows, cols_per_row))
-    return ids.reshape(-1).to(torch.int32).contiguous()
+    return HF.memo("row_index", (ids,), lambda: ids.reshape(-1).to(torch.int32).contiguous(), (rows, cols_per_row))
 
 
 class SubEmbeddings(nn.Module):
@@ -101,8 +104,12 @@ class FrameEmbeddings(nn.Module):
     def forward(self, frame_feat, position_ids=None):
         B, Lc, D = frame_feat.shape
         if position_ids is None:
-            position_ids = torch.arange(Lc, device=frame_feat.device).unsqueeze(0)
-        pid = _row_index(position_ids, B, Lc)
+            key = (B, Lc, str(frame_feat.device))
+            pid = _ARANGE.get(key)
+            if pid is None:
+                pid = _ARANGE[key] = torch.arange(Lc, device=frame_feat.device, dtype=torch.int32).repeat(B)
+        else:
+            pid = _row_index(position_ids, B, Lc)
         x = HF.cast(frame_feat, HF.compute_dtype())
         y = HF.embed_ln(x, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
                         _drop(self.dropout, x.device), HF.compute_dtype(),

@@ -130,11 +130,13 @@ class CrossModalTrm(RobertaPreTrainedModel):
     def _flat_gather_index(gather_index, max_vl, max_sl):
         """reference index into cat([img, txt], dim=1) -> flat row index for hero_gather_rows
         (>= 0: img row, <= -2: txt row)."""
-        T = gather_index.shape[0]
-        row = torch.arange(T, device=gather_index.device).unsqueeze(1)
-        g = gather_index.to(torch.int64)
-        flat = torch.where(g < max_vl, row * max_vl + g, -(row * max_sl + (g - max_vl)) - 2)
-        return flat.reshape(-1).to(torch.int32).contiguous()
+        def build():
+            T = gather_index.shape[0]
+            row = torch.arange(T, device=gather_index.device).unsqueeze(1)
+            g = gather_index.to(torch.int64)
+            flat = torch.where(g < max_vl, row * max_vl + g, -(row * max_sl + (g - max_vl)) - 2)
+            return flat.reshape(-1).to(torch.int32).contiguous()
+        return HF.memo("flat_gather", (gather_index,), build, (max_vl, max_sl))
 
     def _compute_img_txt_embeddings(self, input_ids, position_ids, img_feat, img_pos_ids,
                                     gather_index, txt_type_ids=None, img_type_ids=None,
@@ -247,8 +249,8 @@ class QueryFeatEncoder(nn.Module):
 
     def forward(self, query_feat, query_attn_mask, query_pos_ids=None):
         h = self.query_pos_embed(self.query_input_proj(query_feat), query_pos_ids)
-        m = query_attn_mask.to(torch.float32)
-        ext = ((1.0 - m) * -10000.0)[:, None, None, :]
+        m = HF.memo("mask_f32", (query_attn_mask,), lambda: query_attn_mask.to(torch.float32))
+        ext = HF.as_mask_add(query_attn_mask, m.shape[0], m.shape[1])[:, None, None, :]
         attended = self.query_self_attention(h, ext)[0]
         if self.modularized and self.fused_pool:
             from ..head import QueryPoolFn

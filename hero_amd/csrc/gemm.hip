@@ -239,6 +239,7 @@ struct GemmArgs {
   void* C;
   int M, N, K, lda, ldb, ldc;
   int tiles_m, tiles_n, k_per_split;
+  int group;            // M-tiles per L2 locality group (tile_coord)
   HeroGemmEpilogue epi;
 };
 
@@ -396,7 +397,7 @@ __device__ __forceinline__ TileCoord tile_coord(const GemmArgs& g) {
   const int ntile = g.tiles_m * g.tiles_n;
   const int split = wg / ntile;
   const int tile = wg - split * ntile;
-  constexpr int GROUP = 8;
+  const int GROUP = g.group;
   const int per_group = GROUP * g.tiles_n;
   const int group = tile / per_group;
   const int first_m = group * GROUP;
@@ -735,6 +736,7 @@ struct ProfSlot {
 static ProfSlot g_prof[8];
 static bool g_prof_on = false;
 static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2); -1 = heuristic
+static int g_group = 0;        // tuning hook: M-tiles per locality group (0 = heuristic)
 
 typedef Cfg<2, 2, 2, 2> Cfg128;
 typedef Cfg<2, 4, 4, 2> Cfg256;
@@ -939,6 +941,9 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.tiles_m = g.tiles_n = 0;
+  // M-tiles per L2 locality group (tools/gemm_group_sweep.py): wide outputs like 16 (N = 3072: -4 %),
+  // narrow ones 4 (N = 768: -2 %), 8 in between
+  g.group = g_group ? g_group : (N >= 2560 ? 16 : (N <= 1024 ? 4 : 8));
   g.epi = *epi;
   const int bk = dtype == HERO_BF16 ? 64 : 32;
   const bool k_contig = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
@@ -974,6 +979,7 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
 extern "C" int hero_gemm_force_config(int cfg) {
   g_force_cfg = cfg >= 0 ? (cfg & 3) : -1;
   g_use_glds = cfg >= 0 ? !(cfg & 4) : 1;      // bit 2 set: register staging even for K,K operands
+  g_group = cfg >= 0 ? (cfg >> 8) : 0;         // bits 8+: M-tiles per locality group (0 = heuristic)
   return HERO_OK;
 }
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "hero_last_error", "hero_abi_version", "hero_gemm", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len",
-    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast",
+    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
     "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
@@ -84,6 +84,11 @@ class AdamWMulti(C.Structure):
                 ("n_chunks", C.c_int), ("groups", AdamWGroup * 8), ("step", C.c_int),
                 ("grad_sumsq", C.c_void_p), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float),
                 ("step_ptr", C.c_void_p), ("lr_ptr", C.c_void_p)]
+
+
+class CopyDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("ldd", C.c_int32), ("transpose", C.c_int32), ("dst_dtype", C.c_int32), ("pad_", C.c_int32)]
 
 
 class QueryPool(C.Structure):
@@ -167,6 +172,7 @@ def lib():
         L.hero_sumsq.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hero_adamw.argtypes = [C.POINTER(AdamW), C.c_void_p]
         L.hero_adamw_multi.argtypes = [C.POINTER(AdamWMulti), C.c_void_p]
+        L.hero_copy_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         for fn, st in (("hero_query_pool_fwd", QueryPool), ("hero_query_pool_bwd", QueryPool),
                        ("hero_rownorm_fwd", RowNorm), ("hero_rownorm_bwd", RowNorm),
                        ("hero_score_max_fwd", ScoreMax), ("hero_score_max_bwd", ScoreMax),

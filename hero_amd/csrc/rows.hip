@@ -93,6 +93,44 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+// one 64 x 64 tile of one tensor per workgroup (see hero_copy_multi)
+__global__ __launch_bounds__(256) void copy_multi_kernel(const HeroCopyDesc* __restrict__ descs, const int32_t* __restrict__ tile_desc,
+                                                         const int32_t* __restrict__ tile_index) {
+  __shared__ float tile[64][65];
+  const HeroCopyDesc d = descs[tile_desc[blockIdx.x]];
+  const int tcols = (d.cols + 63) >> 6;
+  const int ti = tile_index[blockIdx.x];
+  const int r0 = (ti / tcols) * 64, c0 = (ti % tcols) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
+  if (!d.transpose) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + ty + 4 * k, c = c0 + tx;
+      if (r < d.rows && c < d.cols) {
+        const float v = d.src[(size_t)r * d.cols + c];
+        if (d.dst_dtype == HERO_BF16) static_cast<bf16_t*>(d.dst)[(size_t)r * d.ldd + c] = f2bf(v);
+        else static_cast<float*>(d.dst)[(size_t)r * d.ldd + c] = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = r0 + ty + 4 * k, c = c0 + tx;
+    tile[ty + 4 * k][tx] = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = c0 + ty + 4 * k, r = r0 + tx;
+    if (c < d.cols && r < d.rows) {
+      const float v = tile[tx][ty + 4 * k];
+      if (d.dst_dtype == HERO_BF16) static_cast<bf16_t*>(d.dst)[(size_t)c * d.ldd + r] = f2bf(v);
+      else static_cast<float*>(d.dst)[(size_t)c * d.ldd + r] = v;
+    }
+  }
+}
+
 template <typename T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, size_t n) {
   const size_t n4 = n >> 2;
@@ -335,6 +373,14 @@ extern "C" int hero_transpose_cast(const float* src, void* dst, int rows, int co
   else if (dst_dtype == HERO_F32) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, rows, cols, ldd);
   else { set_error("hero_transpose_cast: bad dtype %d", dst_dtype); return HERO_ERR_ARG; }
   return check_launch("hero_transpose_cast");
+}
+
+extern "C" int hero_copy_multi(const HeroCopyDesc* descs, const int32_t* tile_desc, const int32_t* tile_index, int n_tiles,
+                               hero_stream_t stream) {
+  HERO_REQUIRE(descs && tile_desc && tile_index, "hero_copy_multi: null pointer");
+  if (n_tiles <= 0) return HERO_OK;
+  hipLaunchKernelGGL(copy_multi_kernel, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), descs, tile_desc, tile_index);
+  return check_launch("hero_copy_multi");
 }
 
 extern "C" int hero_relu_bwd(const void* dy, const void* y, void* dx, size_t n, int dtype, hero_stream_t stream) {

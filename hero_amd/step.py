@@ -75,8 +75,7 @@ class TrainStep:
                             grad_scale=1.0 / D.world_size(), skip=set(untouched),
                             step_tensor=self._step_t if device_state else None,
                             lr_tensor=self._lr_t if device_state else None)
-        if device_state:
-            HF.refresh_weight_cache()
+        HF.refresh_weight_cache()                    # all bf16 / transposed weight copies, one launch
         self.arena.zero()
 
     def _set_lr(self):

@@ -252,6 +252,24 @@ typedef struct HeroAdamWMulti {
 int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream);
 int hero_adamw_multi_chunk(void);
 
+/* Multi-tensor refresh of the compute copies of the fp32 master weights (after an optimiser     */
+/* step): ONE launch casts / transposes every tensor of a device-resident descriptor table.     */
+/*   transpose == 0: dst[r * ldd + c]        = (dst_dtype) src[r * cols + c]                      */
+/*   transpose == 1: dst[c * ldd + r]        = (dst_dtype) src[r * cols + c]                      */
+/* (dst already points at the tensor's slot inside a packed [sum N, K] / [K, sum N] buffer.)     */
+/* Work is cut into tiles of 64 x 64 elements: tile_desc[t] = descriptor, tile_index[t] = tile   */
+/* number inside it (row-major over ceil(rows/64) x ceil(cols/64)).                              */
+typedef struct HeroCopyDesc {
+  const float* src;
+  void* dst;
+  int32_t rows, cols, ldd;
+  int32_t transpose;
+  int32_t dst_dtype;
+  int32_t pad_;
+} HeroCopyDesc;
+int hero_copy_multi(const HeroCopyDesc* descs, const int32_t* tile_desc, const int32_t* tile_index,
+                    int n_tiles, hero_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* VSM / VCMR task head - model/pretrain.py:62-116,128-201,203-292,  */
 /* model/encoder.py:460-471.  The few hundred tiny fp32 tensor ops between the encoders and the  */

@@ -83,3 +83,31 @@ def test_first_optimizer_step_matches_reference_numbers():
               "v_encoder.c_encoder.encoder.layer.0.attention.self.key.bias"):
         assert rel_err(got[k], Pq[k]) < 2e-4, k
     HF.set_grad_sink(None)
+
+
+def test_one_launch_weight_refresh_equals_per_tensor_casts():
+    """HF.refresh_weight_cache (hero_copy_multi) rewrites every cached bf16 / transposed / packed copy
+    exactly like the per-tensor hero_cast / hero_transpose_cast path that first filled the cache."""
+    import hero_amd
+    from hero_amd import functional as HF
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.clear_weight_cache()
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(n, 96, device="cuda")) for n in (64, 130, 40)]
+    bs = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (64, 130, 40)]
+    try:
+        W = HF.packed(ws, torch.bfloat16)
+        Wt = HF.packed_t(ws, torch.bfloat16)
+        B = HF.packed(bs, torch.float32)
+        with torch.no_grad():
+            for p in ws + bs:
+                p.mul_(1.5).add_(0.25)
+        HF.notify_weights_updated()
+        HF.refresh_weight_cache()
+        ref = torch.cat([p.detach() for p in ws], 0)
+        assert HF.packed(ws, torch.bfloat16) is W and HF.packed_t(ws, torch.bfloat16) is Wt   # cache hits, same buffers
+        torch.testing.assert_close(W, ref.to(torch.bfloat16), rtol=0, atol=0)
+        torch.testing.assert_close(Wt, ref.t().contiguous().to(torch.bfloat16), rtol=0, atol=0)
+        torch.testing.assert_close(HF.packed(bs, torch.float32), torch.cat([p.detach() for p in bs]), rtol=0, atol=0)
+    finally:
+        HF.clear_weight_cache()

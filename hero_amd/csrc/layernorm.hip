@@ -336,9 +336,13 @@ __global__ __launch_bounds__(256) void colred_final_kernel(const float* pg, cons
                                                            int nchunks, float beta) {
   const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
+  // gridDim.z > 1 (only with beta == 1): each z-slice folds its share of the chunks and adds it with
+  // fp32 atomics (8-way contention), as in colred_final3_kernel
+  const int per = (nchunks + gridDim.z - 1) / gridDim.z;
+  const int k0 = blockIdx.z * per, k1 = min(nchunks, k0 + per);
   float sg = 0.f, sb = 0.f;
   if (c < cols) {
-    for (int k = kl; k < nchunks; k += 16) {
+    for (int k = k0 + kl; k < k1; k += 16) {
       if (og) sg += pg[(size_t)k * cols + c];
       if (ob) sb += pb[(size_t)k * cols + c];
     }
@@ -355,6 +359,11 @@ __global__ __launch_bounds__(256) void colred_final_kernel(const float* pg, cons
   if (threadIdx.x < 16 && c < cols) {
     sg = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
     sb = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if (gridDim.z > 1) {
+      if (og) atomicAdd(og + c, sg);
+      if (ob) atomicAdd(ob + c, sb);
+      return;
+    }
     if (og) og[c] = (beta != 0.f ? beta * og[c] : 0.f) + sg;
     if (ob) ob[c] = (beta != 0.f ? beta * ob[c] : 0.f) + sb;
   }
@@ -382,7 +391,8 @@ static int run_colred(const void* x, const void* dy, const float* mean, const fl
   hipLaunchKernelGGL((colred_kernel<TX, T>), dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, a);
   int rc = check_launch("colred");
   if (rc || a.atomic) return rc;
-  hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
+  const int zs = (beta == 1.f && nchunks >= 128) ? 8 : 1;
+  hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 15) / 16, 1, zs), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
                      nchunks, beta);
   return check_launch("colred_final");
 }

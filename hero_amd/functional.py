@@ -432,7 +432,7 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
     if want_params and dg is None and db is None:
         dg = torch.empty((cols,), dtype=torch.float32, device=dev)
         db = torch.empty((cols,), dtype=torch.float32, device=dev)
-    ws = _workspace(1536 * cols, dev) if (dg is not None or db is not None or dbias_in is not None) else None
+    ws = _workspace(3072 * cols, dev) if (dg is not None or db is not None or dbias_in is not None) else None
     a = L.LnBwd()
     a.x, a.dy, a.gamma, a.mean, a.rstd = L.ptr(x2), L.ptr(dy2), L.ptr(gamma), L.ptr(mean), L.ptr(rstd)
     a.dx, a.dx_dropped, a.dgamma, a.dbeta = L.ptr(dx), L.ptr(dxd), L.ptr(dg), L.ptr(db)

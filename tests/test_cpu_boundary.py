@@ -173,3 +173,36 @@ def test_grad_arena_groups_are_contiguous():
         assert sum(b[2] for b in arena.buckets) == len(ps)
     finally:
         HF.set_grad_sink(None)
+
+
+def test_pack_plan_maps_are_consistent():
+    """BertEncoder._pack_plan (host logic of the packed ragged path): gather / inverse / per-group maps
+    and sequence offsets describe the same permutation; dense batches get no plan."""
+    import torch
+    from hero_amd.model.layers import BertEncoder
+    BertEncoder._PLANS.clear()
+    m1 = torch.tensor([[1, 1, 1, 0, 0], [0, 1, 1, 1, 1], [1, 0, 0, 0, 0]])       # subtitle rows (one frameless)
+    m2 = torch.tensor([[1, 1, 0], [1, 1, 1]])                                      # query rows
+    plan = BertEncoder._pack_plan([m1, m2], [15, 6])
+    assert plan is not None
+    gather, inverse, inv, back, off, n_seq, lmax = plan
+    flat = torch.cat([m1.reshape(-1), m2.reshape(-1)]).bool()
+    assert gather.tolist() == torch.nonzero(flat).reshape(-1).tolist()
+    assert n_seq == 5 and lmax == 4 and off.tolist() == [0, 3, 7, 8, 10, 13]
+    assert (inverse >= 0).sum() == flat.sum() and torch.equal(inverse[gather.long()], torch.arange(13, dtype=torch.int32))
+    # per group: padded position -> packed row (or -1), packed row -> padded position of that group (or -1)
+    assert inv[0].tolist() == [0, 1, 2, -1, -1, -1, 3, 4, 5, 6, 7, -1, -1, -1, -1]
+    assert inv[1].tolist() == [8, 9, -1, 10, 11, 12]
+    assert back[0].tolist() == [0, 1, 2, 6, 7, 8, 9, 10, -1, -1, -1, -1, -1]
+    assert back[1].tolist() == [-1] * 8 + [0, 1, 3, 4, 5]
+    dense = torch.ones(4, 6, dtype=torch.long)
+    assert BertEncoder._pack_plan([dense], [24]) is None                          # nothing to drop
+    BertEncoder._PLANS.clear()
+
+
+def test_wgrad_split_model_choices():
+    """functional._split_for: the reduction split of dW = dY^T X per step shape (fitted on MI355X)."""
+    from hero_amd.functional import _split_for
+    assert _split_for(3072, 768, 12000, 64) == 3 and _split_for(2304, 768, 12000, 64) == 4
+    assert _split_for(768, 768, 12000, 64) in (6, 7) and _split_for(768, 4352, 1920, 64) == 1
+    assert _split_for(768, 768, 64, 64) == 1                                       # never more splits than K tiles allow

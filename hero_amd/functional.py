@@ -642,8 +642,14 @@ class EmbedLnFn(torch.autograd.Function):
             idx = ctx.idxs[k] if k < len(ctx.idxs) else None
             skip = ctx.skip[k] if ctx.skip else -1
             if _is_param(tab):
+                per = getattr(idx, "_hero_period", 0) if idx is not None else 0
                 if idx is None:
                     k_colsum(dx, out=SINK.dst(tab).view(-1, tab.shape[-1])[0], beta=1.0)
+                elif per and dx.shape[0] % per == 0 and dx.shape[0] // per >= 8:
+                    # periodic index (position ids broadcast over the sequences): fold the repeats with a
+                    # column sum over [S, period*D], then scatter `period` rows - not S-way contended atomics
+                    folded = k_colsum(dx.view(dx.shape[0] // per, per * dx.shape[1]))
+                    k_scatter_add(folded.view(per, dx.shape[1]), idx[:per], SINK.dst(tab), None, skip)
                 else:
                     k_scatter_add(dx, idx, SINK.dst(tab), None, skip)
                 SINK.done(tab)

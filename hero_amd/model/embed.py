@@ -11,15 +11,21 @@ _ARANGE = {}
 
 
 def _row_index(ids, rows, cols_per_row):
-    """Per-output-row int32 table index from the reference's (1, L) or (S, L) id tensors."""
+    """Per-output-row int32 table index from the reference's (1, L) or (S, L) id tensors.  A (1, L)
+    tensor broadcast over the rows gives a PERIODIC index; that is recorded on the result
+    (`_hero_period`) so the backward can sum the S repeats first instead of scatter-adding S-fold
+    contended rows (functional.EmbedLnFn)."""
     if ids.dim() == 1:
         ids = ids.unsqueeze(0)
+    period = cols_per_row if (ids.shape[0] == 1 and rows > 1) else 0
     if ids.shape[0] == 1 and rows > 1:
         ids = ids.expand(rows, -1)
     if ids.shape != (rows, cols_per_row):
         raise ValueError("index tensor of shape %s does not match (%d, %d)" %
                          (tuple(ids.shape), rows, cols_per_row))
-    return HF.memo("row_index", (ids,), lambda: ids.reshape(-1).to(torch.int32).contiguous(), (rows, cols_per_row))
+    out = HF.memo("row_index", (ids,), lambda: ids.reshape(-1).to(torch.int32).contiguous(), (rows, cols_per_row))
+    out._hero_period = period
+    return out
 
 
 class SubEmbeddings(nn.Module):
@@ -108,6 +114,7 @@ class FrameEmbeddings(nn.Module):
             pid = _ARANGE.get(key)
             if pid is None:
                 pid = _ARANGE[key] = torch.arange(Lc, device=frame_feat.device, dtype=torch.int32).repeat(B)
+                pid._hero_period = Lc if B > 1 else 0
         else:
             pid = _row_index(position_ids, B, Lc)
         x = HF.cast(frame_feat, HF.compute_dtype())

@@ -128,6 +128,12 @@ class TrainStep:
             self._optimise(device_state=True)
         self._graphs = (ga, loss_a, gb, loss_b, batch)
 
+    def prepare(self, batch):
+        """One-time setup outside any timed region: in graph mode the eager warm-up micro-steps and the
+        capture of the two graphs on `batch`'s buffers (a no-op otherwise / when already done)."""
+        if self.use_graph and self._graphs is None:
+            self._capture(batch)
+
     def _graph_step(self, batch):
         if self._graphs is None:
             self._capture(batch)

@@ -131,8 +131,13 @@ class TrainStep:
     def prepare(self, batch):
         """One-time setup outside any timed region: in graph mode the eager warm-up micro-steps and the
         capture of the two graphs on `batch`'s buffers (a no-op otherwise / when already done)."""
-        if self.use_graph and self._graphs is None:
-            self._capture(batch)
+        if self.use_graph:
+            if self._graphs is None:
+                self._capture(batch)
+        elif not getattr(self, "_prepared", False):
+            for _ in range(self.opts.gradient_accumulation_steps):   # one full cycle: every lazy state exists
+                self.micro_step(batch)
+            self._prepared = True
 
     def _graph_step(self, batch):
         if self._graphs is None:

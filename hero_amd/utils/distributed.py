@@ -286,6 +286,9 @@ def _host_group():
             _HOST_GROUP[1] = None
         else:
             try:
+                import os
+                if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # single node: no hostname lookups
                 _HOST_GROUP[1] = dist.new_group(backend="gloo")
             except Exception:                     # no usable host interface: sizes travel through RCCL
                 _HOST_GROUP[1] = "device"

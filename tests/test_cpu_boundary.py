@@ -206,3 +206,27 @@ def test_wgrad_split_model_choices():
     assert _split_for(3072, 768, 12000, 64) == 3 and _split_for(2304, 768, 12000, 64) == 4
     assert _split_for(768, 768, 12000, 64) in (6, 7) and _split_for(768, 4352, 1920, 64) == 1
     assert _split_for(768, 768, 64, 64) == 1                                       # never more splits than K tiles allow
+
+
+def test_memo_tracks_identity_and_version():
+    """functional.memo caches tensors derived from batch index / mask tensors: hit on the same object,
+    miss after an in-place edit (version bump), after a shape-changing view, and for another object."""
+    import torch
+    from hero_amd import functional as HF
+    calls = []
+    ids = torch.arange(6).view(2, 3)
+
+    def derive():
+        calls.append(1)
+        return ids.reshape(-1).to(torch.int32)
+    a = HF.memo("t", (ids,), derive)
+    b = HF.memo("t", (ids,), derive)
+    assert a is b and len(calls) == 1
+    ids.add_(1)                                            # in-place edit -> new version -> recomputed
+    c = HF.memo("t", (ids,), derive)
+    assert c is not a and len(calls) == 2 and c.tolist() == [1, 2, 3, 4, 5, 6]
+    HF.memo("t", (ids,), derive, extra=(1,))               # a different `extra` is a different entry
+    assert len(calls) == 3
+    other = ids.clone()
+    HF.memo("t", (other,), derive)
+    assert len(calls) == 4

@@ -34,7 +34,7 @@ class Dropout(C.Structure):
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
                 ("act", C.c_int), ("out_f32", C.c_int), ("beta", C.c_float),
-                ("split_k", C.c_int), ("dropout", Dropout)]
+                ("split_k", C.c_int), ("dropout", Dropout), ("colsum", C.c_void_p)]
 
 
 class LnFwd(C.Structure):

@@ -301,6 +301,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   // behind the staging and its barrier); batches of 4 left ~4 exposed round trips per tile.
   constexpr bool PRE = !GEN && sizeof(T) == 2;
   constexpr int UN = PRE ? ITERS : 4;
+  // column sums of the stored values (bias gradient of the producing layer): generic + gelu' variants
+  constexpr bool CSUM = GEN || (EK & EK_GELU_BWD);
+  const bool do_csum = CSUM && e.colsum != nullptr;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
   for (int pass = 0; pass < PASSES; ++pass) {
     uint2 pre_r[PRE ? ITERS : 1], pre_u[PRE ? ITERS : 1];
@@ -373,6 +377,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
           v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
         }
         if (R) { v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w; }
+        if (do_csum && ok[u]) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
         if (out_f32) {
           if (ld_c) { v.x += e.beta * cc[u].x; v.y += e.beta * cc[u].y; v.z += e.beta * cc[u].z; v.w += e.beta * cc[u].w; }
           if (ok[u]) *reinterpret_cast<float4*>(static_cast<float*>(g.C) + off[u]) = v;
@@ -380,6 +385,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
           if (ok[u]) V4<T>::st(static_cast<T*>(g.C) + off[u], v);
         }
       }
+    }
+  }
+  if (do_csum) {                                   // fold the NT / C4 row groups through LDS, one atomic per column
+    __syncthreads();
+    *reinterpret_cast<float4*>(lc + (threadIdx.x / C4) * BN + c4) = cs;
+    __syncthreads();
+    if (threadIdx.x < C4 && col_ok) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < RSTEP; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(lc + k * BN + c4);
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      atomicAdd(e.colsum + gn, t.x); atomicAdd(e.colsum + gn + 1, t.y); atomicAdd(e.colsum + gn + 2, t.z); atomicAdd(e.colsum + gn + 3, t.w);
     }
   }
 }
@@ -937,6 +956,7 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   HERO_REQUIRE(!epi->residual || (((uintptr_t)epi->residual) & 7) == 0, "hero_gemm: residual misaligned");
   HERO_REQUIRE(!(epi->act == HERO_ACT_GELU || epi->act == HERO_ACT_GELU_BWD || epi->act == HERO_ACT_RELU_BWD) || epi->aux,
                "hero_gemm: activation %d needs aux", epi->act);
+  HERO_REQUIRE(!epi->colsum || (epi->split_k <= 1 && !epi->out_f32), "hero_gemm: epilogue.colsum excludes split_k / out_f32");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -273,10 +273,10 @@ def _p(t):
 
 
 def k_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, al, bl, dtype_code, bias=None, residual=None,
-           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None):
+           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None, colsum=None):
     """A/B/Cm may be tensors or raw device pointers (int) for column-sliced operands."""
     epi = L.GemmEpilogue(_p(bias), _p(residual), _p(aux), act, 1 if out_f32 else 0,
-                         beta, split_k, _d(drop))
+                         beta, split_k, _d(drop), _p(colsum))
     L.check(L.lib().hero_gemm(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, al, bl,
                               dtype_code, C.byref(epi), L.stream()))
 
@@ -301,14 +301,14 @@ def k_dgrad(dy2, Wc, act=L.ACT_NONE, aux=None, residual=None):
     return dx
 
 
-def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None):
+def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None, colsum=None):
     """dx[M,K] = epilogue(dy2[M,N] @ Wt[K,N]^T) with the transposed weight copy: both operands
-    reduction-contiguous -> the direct-to-LDS GEMM path."""
+    reduction-contiguous -> the direct-to-LDS GEMM path.  colsum (fp32 [K]) += column sums of dx."""
     M, N = dy2.shape
     K = Wt.shape[0]
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
     k_gemm(dy2, Wt, dx, M, K, N, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.dt(dy2), act=act, aux=aux,
-           residual=residual)
+           residual=residual, colsum=colsum)
     return dx
 
 
@@ -916,7 +916,11 @@ class FfnBlockFn(torch.autograd.Function):
         if fuse_b:
             SINK.done(b2)
         acc_linear_grads(dy2d, hg, w2, None if fuse_b else b2)
-        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u)       # * gelu'(u), fused
-        acc_linear_grads(du, a2, w1, b1)
+        fuse_b1 = b1.requires_grad
+        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u,       # * gelu'(u), fused; db1 = column sums of du
+                       colsum=SINK.dst(b1) if fuse_b1 else None)   # from the same epilogue
+        acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)
+        if fuse_b1:
+            SINK.done(b1)
         da = k_dgrad_t(du, W1_t, residual=dy2).view(ctx.shp)        # + residual-path gradient, fused
         return (da,) + (None,) * 8

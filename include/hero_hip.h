@@ -69,6 +69,10 @@ typedef struct HeroGemmEpilogue {
   int split_k;          /* >1: reduction split over blocks, fp32 atomics into C (needs       */
                         /*     out_f32, act NONE, no bias/residual/dropout; C pre-scaled)    */
   HeroDropout dropout;  /* applied after bias/act, before residual; index = m*N + n          */
+  float* colsum;        /* optional [N] fp32, ACCUMULATED: colsum[n] += sum_m out[m, n] (the values  */
+                        /* written to C, before rounding).  K,K operands, no split_k.  Gives the     */
+                        /* bias gradient of the layer whose output gradient this GEMM produces        */
+                        /* (dH = (dY W2) * gelu'(u) -> db1) without another pass over dH.             */
 } HeroGemmEpilogue;
 
 /* C[M,N] = op(A)[M,K] * op(B)[K,N] (+ epilogue).

@@ -106,6 +106,25 @@ def test_gemm_forced_geometries(HF, Lb, cfg):
     close(dx, (dy.float() @ w.float()) * gp, dtype, scale=math.sqrt(N) * 0.05 * 2)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(700, 776, 768), (12000, 3072, 768), (130, 64, 64)])
+def test_gemm_output_column_sums(HF, Lb, dtype, M, N, K):
+    """epilogue.colsum: the column sums of the stored output (here dH = (dY W) * gelu'(u), i.e. the FFN1
+    bias gradient) come out of the GEMM that produces it, accumulated into the existing values."""
+    if dtype == torch.float32 and M > 1000:
+        pytest.skip("large shape only in the product dtype")
+    dy = rnd(M, K, dtype=dtype, seed=1)
+    wt = rnd(N, K, dtype=dtype, seed=2, scale=0.05)            # [out features of dx, reduction]
+    u = rnd(M, N, dtype=dtype, seed=3)
+    cs = rnd(N, seed=4)
+    cs0 = cs.clone()
+    dx = HF.k_dgrad_t(dy, wt, act=Lb.ACT_GELU_BWD, aux=u, colsum=cs)
+    ref_dx = HF.k_dgrad_t(dy, wt, act=Lb.ACT_GELU_BWD, aux=u)
+    torch.testing.assert_close(dx, ref_dx, rtol=0, atol=0)
+    want = cs0 + ref_dx.float().sum(0)
+    torch.testing.assert_close(cs, want, rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=0.05 * math.sqrt(M) if dtype == torch.bfloat16 else 1e-3)
+
+
 def test_gemm_transpose_detecting(HF, Lb):
     """A = I with an asymmetric B catches row/column swaps in the MFMA fragment maps."""
     for dtype in DT:

@@ -1,0 +1,1 @@
+"""Data-parallel collectives (RCCL through torch.distributed), gradient arena, training utilities."""

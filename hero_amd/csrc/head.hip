@@ -207,6 +207,12 @@ __global__ __launch_bounds__(256) void score_max_bwd_c_kernel(HeroScoreMax a) {
 // ------------------------------------------------------------------------------------------------
 // D. ranking loss over all in-batch negatives
 // ------------------------------------------------------------------------------------------------
+// (a kernel, not hipMemsetAsync: inside a captured hipGraph every producer / consumer of a buffer
+// should be a kernel node of the same chain)
+__global__ void zero_f32_kernel(float* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 __device__ __forceinline__ void rank_term(const HeroRankLoss& a, float pos, float neg, float& l, float& g) {
   if (a.lse) {
     const float z = neg - pos;
@@ -459,7 +465,10 @@ extern "C" int hero_rank_loss(const HeroRankLoss* a, hero_stream_t stream) {
   HERO_REQUIRE(a->nv > 1 && a->nq >= a->nv && a->nq % a->nv == 0, "hero_rank_loss: need nv > 1 and nq a multiple of nv (nq=%d nv=%d)",
                a->nq, a->nv);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(a->ds_q, 0, sizeof(float) * (size_t)a->nq * a->nv, s) != hipSuccess) return check_launch("hero_rank_loss(memset)");
+  {
+    const size_t n = (size_t)a->nq * a->nv;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s, a->ds_q, n);
+  }
   hipLaunchKernelGGL(rank_loss_kernel, dim3(a->nq, 2), dim3(256), 0, s, *a);
   return check_launch("hero_rank_loss");
 }

@@ -507,7 +507,7 @@ extern "C" int hero_colsum(const void* x, float* out, int rows, int cols, int ld
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeroDropout none = {nullptr, 0, 0, 1.f};
   if (rows <= 0) {
-    if (beta == 0.f) (void)hipMemsetAsync(out, 0, sizeof(float) * cols, s);
+    if (beta == 0.f) hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, nullptr, nullptr, nullptr, out, cols, 0, 0.f);   // zeros (a kernel node, not a memset)
     return HERO_OK;
   }
   if (dtype == HERO_F32) return run_colred<float, float>(nullptr, x, nullptr, nullptr, nullptr, out, rows, cols, ld, beta, none, workspace, s);

@@ -230,3 +230,17 @@ def test_memo_tracks_identity_and_version():
     other = ids.clone()
     HF.memo("t", (other,), derive)
     assert len(calls) == 4
+
+
+def test_no_memset_nodes_in_the_kernel_library():
+    """hipMemsetAsync inside a captured hipGraph is not ordered like the kernel nodes around it on this
+    stack (round 1: the ranking-loss buffer was zeroed by a memset node that raced with the kernel that
+    accumulates into it whenever the queue was idle -> late-training collapses in graph mode only).
+    Buffers are zeroed by kernels; keep it that way."""
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hero_amd", "csrc")
+    for path in glob.glob(os.path.join(root, "*")):
+        if path.endswith((".hip", ".cpp", ".h")):
+            code = "\\n".join(line.split("//")[0] for line in open(path).read().splitlines())
+            assert "hipMemset" not in code, path

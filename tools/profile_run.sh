@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o s -
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --profile-steps 0 > /dev/null 2> $OUT/${TAG}_pmcf.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --profile-steps 0 > /dev/null 2> $OUT/${TAG}_pmcw.log
 cd $ROOT
-python tools/profile_summary.py stats $OUT/${TAG}_stats 10 $OUT/${TAG}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph (MI355X)"
+python tools/profile_summary.py stats $OUT/${TAG}_stats 12 $OUT/${TAG}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph (MI355X)"
 python tools/profile_summary.py pmc $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_traffic.json
 # raw per-dispatch traces are large; keep only the summaries + stats csv
 rm -f $OUT/${TAG}_pmc_fetch/*/*counter_collection.csv $OUT/${TAG}_pmc_write/*/*counter_collection.csv 2>/dev/null

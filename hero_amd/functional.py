@@ -12,7 +12,6 @@ Block structure (one autograd node each, residual fan-in fused into GEMM epilogu
 import ctypes as C
 import math
 
-import os
 import torch
 
 from . import _lib as L

@@ -11,8 +11,6 @@ MI355X-first additions: GradArena keeps all gradients in ONE flat fp32 buffer th
 accumulates into in place, so buckets are all-reduced straight out of it (no flatten/unflatten
 copies) and are launched from autograd hooks while the rest of backward is still running.
 """
-import pickle
-
 import torch
 import torch.distributed as dist
 
@@ -341,4 +339,4 @@ def any_broadcast(data, root_rank):
 
 
 __all__ = ["all_reduce_and_rescale_tensors", "broadcast_tensors", "GradArena", "gather_negatives",
-           "all_gather_list", "any_broadcast", "world_size", "rank", "pickle"]
+           "all_gather_list", "any_broadcast", "world_size", "rank"]

@@ -130,7 +130,8 @@ def main():
     with open(cfg_path, "w") as f:
         json.dump(HERO_BASE, f)
     model = build_model(device, cfg_path)
-    trainer = TrainStep(model, use_graph=(world == 1 and not args.no_graph))
+    trainer = TrainStep(model, use_graph=(world == 1 and not args.no_graph),
+                        static_usage=True)     # drop_svmr_prob = 0: every step uses the same parameters
     batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device)
     sh = SHAPES["D2"]
 

@@ -138,12 +138,12 @@ class HierarchicalVlModel(VideoPreTrainedModel):
     def _frame_map(self, num_subs, sub2frm, B, NF, Lf, device):
         key = (id(sub2frm), tuple(num_subs), B, NF, Lf, str(device))
         hit = self._frame_maps.get(key)
-        if hit is None:
+        if hit is None or hit[0] is not sub2frm:      # the entry keeps its source alive: ids are not reused
             if len(self._frame_maps) > 64:
                 self._frame_maps.clear()
-            hit = build_frame_map(num_subs, sub2frm, B, NF, Lf, device)
+            hit = (sub2frm, build_frame_map(num_subs, sub2frm, B, NF, Lf, device))
             self._frame_maps[key] = hit
-        return hit
+        return hit[1]
 
     def collect_frame_outputs(self, out_shape, frame_sequence_output, num_subs, sub_idx2frame_idx):
         B, NF, D = out_shape

@@ -38,9 +38,11 @@ def qkv_groups(model):
 
 
 class TrainStep:
-    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=True):
-        """static_usage: every step touches the same parameters (single-task fine-tuning) - lets the
-        gradient buckets that also hold never-used parameters overlap with backward too."""
+    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=False):
+        """static_usage: the set of parameters that receive gradients only grows over the run (single-task
+        fine-tuning with drop_svmr_prob = 0, as bench.py runs it) - lets the gradient buckets that also
+        hold never-used parameters overlap with backward too.  Off by default: the reference configs
+        drop the st/ed head on 80 % of the steps (config/train-tvr-8gpu.json:30)."""
         self.model = model
         self.opts = SimpleNamespace(**{**TVR_OPTS, **(opts or {})})
         self.task = task

@@ -197,10 +197,19 @@ class GradArena(HF.GradSink):
         self._final.add(p)
         if not (self.sync and self.overlap) or world_size() == 1:
             return
-        if self._expect is not None and p not in self._expect:
-            raise RuntimeError("GradArena(static_usage=True): a parameter of shape %s received a gradient "
-                               "in this step but not in the previous one" % (tuple(p.shape),))
         b = self.bucket_of[p]
+        if self._expect is not None and p not in self._expect:
+            # a parameter that no earlier step touched (e.g. the st/ed head after steps that dropped it,
+            # model/pretrain.py:74-75): its bucket was not counting on it.  Still correct if the bucket
+            # has not been issued yet - hold it back for finish() and expect the parameter from now on.
+            if self._launched[b]:
+                raise RuntimeError("GradArena(static_usage=True): a parameter of shape %s received its first "
+                                   "gradient after its bucket's all-reduce was issued; construct the arena "
+                                   "with static_usage=False for steps that change the set of used "
+                                   "parameters" % (tuple(p.shape),))
+            self._expect = self._expect | {p}
+            self._pending[b] = 1 << 30
+            return
         self._pending[b] -= 1
         if self._pending[b] == 0:
             self._launch(b)
@@ -228,7 +237,9 @@ class GradArena(HF.GradSink):
                 h.wait()
         self._handles = []
         if self.static_usage and self.touched:
-            self._expect = frozenset(self.touched)
+            # union over all steps so far: a parameter that is used only on some steps (drop_svmr_prob,
+            # task mixes) keeps its bucket waiting for finish() on the steps that skip it
+            self._expect = frozenset(self.touched) | (self._expect or frozenset())
         if self._expect is not None:
             self._pending = [0] * len(self.buckets)
             for p in self._expect:

@@ -87,7 +87,9 @@ int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
 /* Per-launch timing of hero_gemm with HIP events recorded on the launch stream (bench.py's
  * roofline leg; off by default, never enable inside graph capture).
  * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout. hero_prof_read synchronises. */
-int hero_gemm_force_config(int cfg); /* tuning hook: 0 128x128, 1 128x256, 2 256x256, -1 heuristic */
+int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
+                                      * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
+                                      * bits 8+: M-tiles per L2 locality group; -1 heuristic */
 int hero_prof_enable(int on);
 int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches);
 

@@ -55,6 +55,41 @@ def test_struct_layouts_match_header_sizes(built_lib):
     assert mine == sizes
 
 
+def test_integration_md_ctypes_snippet_matches_header():
+    """The ctypes mirrors printed in INTEGRATION.md are what a maintainer copies: every struct defined
+    there must have the header's size and field offsets (a stale mirror hands kernels garbage)."""
+    import subprocess
+    import tempfile
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "class GemmEpilogue" in b)
+    classes = "\n".join(m.group(0) for m in re.finditer(r"^class \w+\(C\.Structure\):\n(?:    .*\n?|\s*\n)+?(?=^\S|\Z)",
+                                                         code, flags=re.M))
+    ns = {"C": ctypes}
+    exec(classes, ns)
+    mirrors = {k: v for k, v in ns.items() if isinstance(v, type) and issubclass(v, ctypes.Structure)}
+    assert {"Dropout", "GemmEpilogue"} <= set(mirrors)
+    lines = []
+    for name, cls in sorted(mirrors.items()):
+        cname = "Hero" + name
+        lines.append('printf("%s %%zu", sizeof(%s));' % (name, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f))
+        lines.append('printf("\\n");')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "hero_hip.h"\nint main(){%s return 0;}\n' % "".join(lines)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "s.c"), "w") as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"),
+                               "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().splitlines()
+    for line in out:
+        name, size, *offs = line.split()
+        cls = mirrors[name]
+        assert ctypes.sizeof(cls) == int(size), name
+        assert [getattr(cls, f).offset for f, _ in cls._fields_] == list(map(int, offs)), name
+
+
 def test_state_dict_schema_equals_reference():
     from hero_amd.model import HeroForVcmr
     z = np.load(os.path.join(GOLDEN, "tiny_model.npz"))

@@ -121,6 +121,61 @@ def test_grad_arena_bucketed_allreduce():
     assert all(spawn(_arena))
 
 
+def _arena_intermittent(rank, world):
+    """static_usage with a parameter that only some steps use (the st/ed head under drop_svmr_prob,
+    model/pretrain.py:74-75): its first appearance holds its bucket back for finish(); afterwards
+    the bucket waits for it and falls back to finish() on the steps that skip it."""
+    from hero_amd import functional as HF
+    from hero_amd.utils import distributed as D
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(6, 6))
+    w2 = torch.nn.Parameter(torch.randn(6, 6))
+    w3 = torch.nn.Parameter(torch.randn(6))
+    arena = D.GradArena([w1, w2, w3], bucket_bytes=64, overlap=True, static_usage=True)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(20 + rank))
+
+    def step(use_w3):
+        arena.set_sync(True)
+        y = (x @ w1) @ w2
+        if use_w3:
+            y = y * w3                                  # used last in forward -> its gradient is final first
+        y.sum().backward()
+        launched = sum(arena._launched)
+        arena.finish()
+        got = [p.grad.clone() for p in (w1, w2, w3)]
+        arena.zero()
+        return launched, got
+
+    def expect(use_w3):
+        out = []
+        for r in range(world):
+            xr = torch.randn(4, 6, generator=torch.Generator().manual_seed(20 + r))
+            a, b, c = (p.detach().clone().requires_grad_() for p in (w1, w2, w3))
+            y = (xr @ a) @ b
+            if use_w3:
+                y = y * c
+            y.sum().backward()
+            out.append([a.grad, b.grad, c.grad if use_w3 else torch.zeros(6)])
+        return [sum(o[i] for o in out) for i in range(3)]
+
+    ok = True
+    seen = []
+    for use in (False, False, True, False, True):
+        launched, got = step(use)
+        seen.append(launched)
+        ok = ok and all(torch.allclose(g, e, atol=1e-5) for g, e in zip(got, expect(use)))
+    # buckets [w3, w2] and [w1]: step 1 nothing is expected yet (w3 never final -> only w1's bucket
+    # overlaps); step 2 both; step 3 w3 appears first -> its bucket is held back; step 4 the bucket now
+    # waits for w3 in vain; step 5 both overlap again
+    ok = ok and seen == [1, 2, 1, 1, 2]
+    HF.set_grad_sink(None)
+    return bool(ok)
+
+
+def test_grad_arena_intermittent_parameter():
+    assert all(spawn(_arena_intermittent))
+
+
 def _negatives(rank, world):
     from hero_amd.utils import distributed as D
     torch.manual_seed(rank)

@@ -556,7 +556,8 @@ static int bwd_by_len(const HeroAttn& a, hipStream_t s) {
   if (a.L <= 128) return launch_bwd<T, LPK, 32>(a, s);
   return launch_bwd<T, LPK, 64>(a, s);
 }
-int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s);   // attention_mfma.hip (bf16, L <= 64)
+int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s);        // attention_mfma.hip (bf16, L <= 64)
+int attn_mfma_long_run(const HeroAttn& a, bool bwd, hipStream_t s);   // attention_mfma_long.hip (bf16, 64 < L <= 256)
 
 static bool use_mfma() {   // tuning hook: HERO_ATTN_MFMA=0 keeps the fp32-VALU kernels for bf16 too
   static const bool on = [] { const char* e = getenv("HERO_ATTN_MFMA"); return !(e && e[0] == '0'); }();
@@ -566,6 +567,13 @@ static bool use_mfma() {   // tuning hook: HERO_ATTN_MFMA=0 keeps the fp32-VALU 
 template <typename T>
 static int run(const HeroAttn& a, bool bwd, hipStream_t s) {
   if (sizeof(T) == 2 && a.L <= 64 && use_mfma()) return attn_mfma_run(a, bwd, s);
+  // longer sequences on the matrix cores too; the backward takes delta_i = dO_i . ctx_i from the forward output
+  if (sizeof(T) == 2 && a.L <= 256 && use_mfma() && (!bwd || a.ctx)) return attn_mfma_long_run(a, bwd, s);
+  if (a.seq_off && a.L > 64) {
+    set_error("hero_attention_%s: packed batches with L = %d > 64 need the bf16 matrix-core kernels (and ctx in the backward)",
+              bwd ? "bwd" : "fwd", a.L);
+    return HERO_ERR_UNSUPPORTED;
+  }
   const int lim = max_len<T>(bwd ? 1 : 0);
   if (a.L > lim) {
     set_error("hero_attention_%s: sequence length %d exceeds the LDS-resident limit %d for this dtype", bwd ? "bwd" : "fwd", a.L, lim);
@@ -585,7 +593,8 @@ static int check_attn(const HeroAttn* a, bool bwd) {
   HERO_REQUIRE(a && a->qkv, "hero_attention: null qkv");
   HERO_REQUIRE(a->S >= 0 && a->L > 0 && a->H > 0, "hero_attention: bad dims S=%d L=%d H=%d", a->S, a->L, a->H);
   HERO_REQUIRE(a->dtype == HERO_F32 || a->dtype == HERO_BF16, "hero_attention: bad dtype %d", a->dtype);
-  HERO_REQUIRE(!a->seq_off || a->L <= 64, "hero_attention: packed batches (seq_off) need L <= 64, got %d", a->L);
+  HERO_REQUIRE(!a->seq_off || a->L <= (a->dtype == HERO_BF16 ? 256 : 64), "hero_attention: packed batches (seq_off) need L <= %d, got %d",
+               a->dtype == HERO_BF16 ? 256 : 64, a->L);
   if (bwd) HERO_REQUIRE(a->probs && a->dctx && a->dqkv, "hero_attention_bwd: probs/dctx/dqkv required");
   else HERO_REQUIRE(a->ctx, "hero_attention_fwd: ctx required");
   return HERO_OK;

@@ -23,7 +23,7 @@
 // takes the masked path.  (A branch around a load makes hipcc wait vmcnt(0) per load.)
 // The epilogue goes through LDS (128 output rows at a time): bias is loaded once per thread, the
 // residual / aux / C loads of four rows are issued together, stores are 8-16 B per lane along N.
-#include "common.h"
+#include "gemm_args.h"
 #include <vector>
 
 namespace hero {
@@ -248,7 +248,6 @@ struct GemmArgs {
 // ---------------------------------------------------------------------------------------------
 // EK selects the epilogue features at COMPILE time for the hot-path combinations (the generic
 // runtime-flag version costs thousands of instructions per thread); EK_GENERIC keeps every flag.
-enum { EK_GENERIC = 0x100, EK_BIAS = 1, EK_GELU = 2, EK_RES = 4, EK_DROP = 8, EK_GELU_BWD = 16 };
 
 template <typename T, typename CF, int EK>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)[CF::TM][CF::TN], char* smem, int m0, int n0,
@@ -754,7 +753,29 @@ struct ProfSlot {
 };
 static ProfSlot g_prof[8];
 static bool g_prof_on = false;
-static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2); -1 = heuristic
+static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2,3), 8 / 9: wave-specialised kernels never / always; -1 = heuristic
+
+struct ProfToken { ProfSlot* ps; hipEvent_t e0; };
+void* gemm_prof_begin(int slot, hipStream_t s) {
+  if (!g_prof_on) return nullptr;
+  ProfSlot* ps = &g_prof[slot & 7];
+  hipEvent_t e0 = nullptr;
+  if (ps->flops.size() >= 16384 || hipEventCreate(&e0) != hipSuccess) return nullptr;
+  (void)hipEventRecord(e0, s);
+  return new ProfToken{ps, e0};
+}
+void gemm_prof_end(void* token, double flops, hipStream_t s) {
+  if (!token) return;
+  ProfToken* t = static_cast<ProfToken*>(token);
+  hipEvent_t e1 = nullptr;
+  if (hipEventCreate(&e1) == hipSuccess) {
+    (void)hipEventRecord(e1, s);
+    t->ps->ev.push_back(t->e0);
+    t->ps->ev.push_back(e1);
+    t->ps->flops.push_back(flops);
+  }
+  delete t;
+}
 static int g_group = 0;        // tuning hook: M-tiles per locality group (0 = heuristic)
 
 typedef Cfg<2, 2, 2, 2> Cfg128;
@@ -797,7 +818,7 @@ static int launch(GemmArgs g, hipStream_t s) {
 // workgroups per CU is the best or within a few % of the best on every shape of the HERO step; the
 // 256x256 tile wins ~5 % on the largest K-contiguous problems only.
 static int pick_cfg(int M, int N, int split, bool k_contig) {
-  if (g_force_cfg >= 0) return g_force_cfg;
+  if (g_force_cfg >= 0 && g_force_cfg < 8) return g_force_cfg;
   if (!k_contig || split != 1) return 0;
   const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
   if (t128 <= 192) return 3;                                                // under one 128^2 tile per CU
@@ -968,6 +989,10 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   const int bk = dtype == HERO_BF16 ? 64 : 32;
   const bool k_contig = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == HERO_BF16) {        // large problems: wave-specialised persistent 192 x 192 tiles (gemm_ws.hip)
+    const int rc = gemm_ws_run(A, B, C, M, N, K, lda, ldb, ldc, a_layout, b_layout, *epi, g_force_cfg, s);
+    if (rc != -1) return rc;
+  }
   if (epi->split_k > 1) {
     HERO_REQUIRE(epi->out_f32 && epi->act == HERO_ACT_NONE && !epi->bias && !epi->residual && epi->dropout.threshold16 == 0,
                  "hero_gemm: split_k supports only a plain fp32 accumulate epilogue");
@@ -997,6 +1022,12 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
 
 // Tuning hook: force a tile geometry (0: 128x128, 1: 192x128, 2: 256x256, 3: 64x64 [1 and 3: direct-to-LDS path only], -1: heuristic).
 extern "C" int hero_gemm_force_config(int cfg) {
+  if (cfg == 8 || cfg == 9) {                  // wave-specialised kernels never / always (4-wave heuristic otherwise)
+    g_force_cfg = cfg;
+    g_use_glds = 1;
+    g_group = 0;
+    return HERO_OK;
+  }
   g_force_cfg = cfg >= 0 ? (cfg & 3) : -1;
   g_use_glds = cfg >= 0 ? !(cfg & 4) : 1;      // bit 2 set: register staging even for K,K operands
   g_group = cfg >= 0 ? (cfg >> 8) : 0;         // bits 8+: M-tiles per locality group (0 = heuristic)

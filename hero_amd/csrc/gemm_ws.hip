@@ -1,0 +1,608 @@
+// Wave-specialised persistent bf16 GEMM for gfx950 (MI355X): the large-M shapes of the HERO step.
+//
+//   K,K operands (forward x W^T, dgrad dY (W^T)^T):   C[M,N] bf16 = A[M,K] B[N,K]^T (+ fused epilogue)
+//   O,O operands (wgrad dW += dY^T X, rows reduced):    C[M,N] fp32 += A[K,M]^T B[K,N], reduction split
+//
+// One 512-thread workgroup per CU, persistent over a static list of work items (output tile x
+// reduction split), tile (64 TM) x (64 TN) x 64:
+//   waves 4-7  LOADERS: issue the direct-to-LDS loads (buffer_load ... lds, 16 B / lane, 1 KiB per
+//              instruction) of the item stream into a 3-stage ring, two stages ahead, counted vmcnt.  The
+//              per-lane offsets are fixed for an item, the k advance moves the descriptor base (SALU),
+//              M0 carries the LDS destination: no VALU per load, and the compute waves' instruction
+//              streams never carry a VMEM issue (60-180 cycles each beside MFMAs).
+//   waves 0-3  COMPUTE (2 x 2, TM x TN MFMA 32x32x16 tiles each): fragments of the next 16-k slice are read
+//              from LDS into a second register set while the MFMAs of the current slice run.
+//   One raw s_barrier per 64-k step hands the ring over (stage t+1 landed / stage t free).  The stream
+//   runs across item boundaries, so the next tile's first two stages land during the epilogue.
+// The 192 x 192 tile is the shape of the step: M = 12000 rows and N = 768 k give 63 x 4 k tiles = 252 k
+// workgroups on 256 CUs (98 % fill for N = 768, 2304, 3072; 256 x 256 tiles fill 55 % of one round at N = 768).
+//
+// Epilogue, K,K: accumulators -> LDS (fp32, the ring slot that was read last, 64 rows per pass, 16-byte
+// chunks XOR-swizzled by row) -> all 8 waves apply bias / GELU / dropout / residual / gelu' on full rows
+// and store 16 B per lane.  The MFMA operands are swapped (D^T = B A^T) so that a lane holds 4
+// consecutive columns of one row: the LDS writes are ds_write_b128.  O,O: fp32 atomics straight from the
+// (unswapped) accumulator layout: 32 consecutive columns per half-wave.
+//
+// LDS images: K,K  [rows][128 B] per operand, 16-B chunk c of row r at chunk c ^ ((r ^ r>>3) & 7)
+//             O,O  [64 k][BM * 2 B], chunk c of row k at c ^ swz(k): the four k-rows a 32-lane half of a
+//                  ds_read_b64_tr_b16 touches land in four distinct 64-B quarters of the bank row
+// (the swizzle is applied on the SOURCE address of the DMA and on the read address).
+// Reduction tail of the O,O flavour (rows % 64 != 0): the loads of rows past the matrix are
+// out-of-range for the buffer descriptor and deliver zeros.
+#include "gemm_args.h"
+
+namespace hero {
+namespace ws {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int NS = 3;                 // ring stages
+constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-sum fold
+
+#define HERO_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct WsArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K, lda, ldb, ldc;       // output M x N, reduction K
+  int tiles_m, tiles_n, group, nsplit, k_per_split, nwork;
+  HeroGemmEpilogue epi;
+};
+
+template <int TM_, int TN_> struct Geo {
+  static constexpr int TM = TM_, TN = TN_;
+  static constexpr int BM = 64 * TM, BN = 64 * TN;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int PA = BM / 32, PB = BN / 32, PW = PA + PB;      // 1-KiB pieces per loader wave per stage
+  static constexpr int ROWB = BN * 4;                                   // fp32 staging row
+  static constexpr int RPP = (STAGE / ROWB >= 64 && BM % 64 == 0) ? 64 : 32;   // rows per epilogue pass
+  static constexpr int PASSES = BM / RPP;
+  static constexpr int C8 = BN / 8, RPI = 512 / C8, ITERS = (RPP + RPI - 1) / RPI;
+  static constexpr int LDS = NS * STAGE > SPARE_OFF ? NS * STAGE : SPARE_OFF + 16384;
+  static_assert(NS * STAGE <= SPARE_OFF && RPP * ROWB <= STAGE && RPI * BN * 4 <= 16384, "LDS budget");
+};
+
+struct Item { int m0, n0, kbeg, nk; };
+
+template <typename G>
+__device__ __forceinline__ Item item_coord(const WsArgs& g, int item) {
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int split = item / ntile;
+  const int tile = item - split * ntile;
+  const int per_group = g.group * g.tiles_n;
+  const int group = tile / per_group;
+  const int first_m = group * g.group;
+  const int gsz = min(g.tiles_m - first_m, g.group);
+  const int in_group = tile - group * per_group;
+  Item it;
+  it.m0 = (first_m + in_group % gsz) * G::BM;
+  it.n0 = (in_group / gsz) * G::BN;
+  it.kbeg = split * g.k_per_split;
+  it.nk = (min(g.K, it.kbeg + g.k_per_split) - it.kbeg + 63) >> 6;
+  return it;
+}
+
+__device__ __forceinline__ int swz_k(int row) { return (row ^ (row >> 3)) & 7; }
+// O,O image: chunk swizzle of reduction row k for a tile row of RB bytes
+template <int RB> __device__ __forceinline__ int swz_o(int k) { return RB % 256 == 0 ? 4 * (k & 3) : 4 * ((k >> 1) & 1); }
+
+// ------------------------------------------------------------------------------------------------
+// loader waves
+// ------------------------------------------------------------------------------------------------
+template <typename G, bool TR>
+struct Loader {
+  const WsArgs& g;
+  char* smem;
+  int w, lane, nwg;
+  int item, ik;           // item / stage being issued next
+  Item ic;
+  unsigned fill;
+  unsigned goa[G::PA], gob[G::PB];
+  const char* pa;         // stage base of the A / B panels (uniform)
+  const char* pb;
+  unsigned ra_left, rb_left;   // bytes from the stage base to the end of the operand (O,O bounds)
+
+  __device__ __forceinline__ Loader(const WsArgs& g_, char* smem_, int wg, int nwg_, int w_, int lane_)
+      : g(g_), smem(smem_), w(w_), lane(lane_), nwg(nwg_), item(wg), ik(0), fill(0) {
+    if (item < g.nwork) setup();
+  }
+  __device__ __forceinline__ void setup() {
+    ic = item_coord<G>(g, item);
+    const bf16_t* A = static_cast<const bf16_t*>(g.A);
+    const bf16_t* B = static_cast<const bf16_t*>(g.B);
+    if (!TR) {
+#pragma unroll
+      for (int i = 0; i < G::PA; ++i) {
+        const int r = (w * G::PA + i) * 8 + (lane >> 3);
+        goa[i] = (unsigned)(min(ic.m0 + r, g.M - 1) - ic.m0) * (unsigned)g.lda * 2u + (((lane & 7) ^ swz_k(r)) << 4);
+      }
+#pragma unroll
+      for (int i = 0; i < G::PB; ++i) {
+        const int r = (w * G::PB + i) * 8 + (lane >> 3);
+        gob[i] = (unsigned)(min(ic.n0 + r, g.N - 1) - ic.n0) * (unsigned)g.ldb * 2u + (((lane & 7) ^ swz_k(r)) << 4);
+      }
+      pa = reinterpret_cast<const char*>(A + (size_t)ic.m0 * g.lda + ic.kbeg);
+      pb = reinterpret_cast<const char*>(B + (size_t)ic.n0 * g.ldb + ic.kbeg);
+      ra_left = rb_left = 0x7fffffffu;
+    } else {
+      constexpr int CA = G::BM / 8, CB = G::BN / 8;      // 16-B chunks per tile row
+#pragma unroll
+      for (int i = 0; i < G::PA; ++i) {
+        const int id = (w * G::PA + i) * 64 + lane, row = id / CA, c = (id % CA) ^ swz_o<G::BM * 2>(row);
+        goa[i] = (unsigned)row * (unsigned)g.lda * 2u + (c << 4);
+      }
+#pragma unroll
+      for (int i = 0; i < G::PB; ++i) {
+        const int id = (w * G::PB + i) * 64 + lane, row = id / CB, c = (id % CB) ^ swz_o<G::BN * 2>(row);
+        gob[i] = (unsigned)row * (unsigned)g.ldb * 2u + (c << 4);
+      }
+      // A is [K, lda] with the tile's M columns at m0; B is [K, ldb] with the N columns at n0
+      pa = reinterpret_cast<const char*>(A + (size_t)ic.kbeg * g.lda + ic.m0);
+      pb = reinterpret_cast<const char*>(B + (size_t)ic.kbeg * g.ldb + ic.n0);
+      ra_left = (unsigned)(((size_t)(g.K - ic.kbeg) * g.lda - ic.m0) * 2);
+      rb_left = (unsigned)(((size_t)(g.K - ic.kbeg) * g.ldb - ic.n0) * 2);
+    }
+  }
+  // issue the next stage of the item stream (false: the stream has ended)
+  __device__ __forceinline__ bool issue() {
+    if (item >= g.nwork) return false;
+    char* buf = smem + fill;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, ra_left, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, rb_left, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < G::PA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G::PB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, 0);
+    fill += G::STAGE;
+    if (fill == NS * G::STAGE) fill = 0;
+    if (++ik == ic.nk) {
+      item += nwg;
+      ik = 0;
+      if (item < g.nwork) setup();
+    } else if (!TR) {
+      pa += 128;
+      pb += 128;
+    } else {
+      const unsigned sa = 64u * (unsigned)g.lda * 2u, sb = 64u * (unsigned)g.ldb * 2u;
+      pa += sa; pb += sb;
+      ra_left = ra_left > sa ? ra_left - sa : 0u;
+      rb_left = rb_left > sb ? rb_left - sb : 0u;
+    }
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// K,K epilogue: run by all 8 waves; the compute waves additionally stage their accumulators
+// ------------------------------------------------------------------------------------------------
+template <typename G, int EK, bool COMPUTE>
+__device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, char* smem, unsigned slot, f32x16_t (*acc)[G::TN], int wave,
+                                              int lane) {
+  constexpr int TM = G::TM, TN = G::TN, BN = G::BN, RPP = G::RPP, C8 = G::C8, RPI = G::RPI, ITERS = G::ITERS;
+  const HeroGemmEpilogue& e = g.epi;
+  char* st = smem + slot;
+  const int tid = threadIdx.x;
+  const int c8 = tid % C8, r0 = tid / C8;
+  const bool active = r0 < RPI;
+  const int gn = ic.n0 + c8 * 8;
+  const bool col_ok = active && gn < g.N;
+  const int gnc = min(gn, g.N - 8);
+  bf16_t* Cb = static_cast<bf16_t*>(g.C);
+  const bf16_t* R = (EK & EK_RES) ? static_cast<const bf16_t*>(e.residual) : nullptr;
+  bf16_t* X = static_cast<bf16_t*>(e.aux);
+  DropCtx drop(e.dropout);
+  const bool use_drop = (EK & EK_DROP) && drop.on();
+  float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (EK & EK_BIAS) {
+    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + gnc);
+    const float4 b1 = *reinterpret_cast<const float4*>(e.bias + gnc + 4);
+    bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+    bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+  }
+  const bool do_csum = (EK & EK_GELU_BWD) && e.colsum != nullptr;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+
+#pragma unroll
+  for (int p = 0; p < G::PASSES; ++p) {
+    // residual / saved pre-activation of this pass: fetched before the accumulators are staged
+    uint4 pre[ITERS];
+    unsigned off[ITERS];
+    bool ok[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = r0 + it * RPI;
+      const int gm = ic.m0 + p * RPP + row;
+      ok[it] = col_ok && row < RPP && gm < g.M;
+      off[it] = (unsigned)min(gm, g.M - 1) * (unsigned)g.ldc + (unsigned)gnc;
+      if (EK & EK_RES) pre[it] = *reinterpret_cast<const uint4*>(R + off[it]);
+      if (EK & EK_GELU_BWD) pre[it] = *reinterpret_cast<const uint4*>(X + off[it]);
+    }
+    if constexpr (COMPUTE) {
+#pragma unroll
+      for (int b = 0; b < RPP / 32; ++b) {
+        const int blk = p * (RPP / 32) + b;          // 32-row block of the tile
+        if (wm == blk / TM) {
+          const int i = blk % TM;                     // compile-time after unrolling
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int chunk = (wn * TN * 32 + j * 32 + 8 * q + 4 * half) >> 2;
+              const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              *reinterpret_cast<f32x4_t*>(st + (32 * b + l31) * G::ROWB + ((chunk ^ (l31 & 7)) << 4)) = v;
+            }
+        }
+      }
+    }
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                    // E1: the pass is staged
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = r0 + it * RPI;
+      if (active && row < RPP) {
+        const int x = row & 7;
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(st + row * G::ROWB + (((2 * c8) ^ x) << 4));
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(st + row * G::ROWB + (((2 * c8 + 1) ^ x) << 4));
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bias[k];
+        if (EK & EK_GELU) {
+          uint4 u;
+          u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
+          if (ok[it]) *reinterpret_cast<uint4*>(X + off[it]) = u;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
+        }
+        float pv[8];                                  // residual / saved pre-activation as fp32
+        if (EK & (EK_RES | EK_GELU_BWD)) {
+          const uint32_t w4[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pv[2 * k] = __uint_as_float(w4[k] << 16);
+            pv[2 * k + 1] = __uint_as_float(w4[k] & 0xffff0000u);
+          }
+        }
+        if (EK & EK_GELU_BWD) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] *= gelu_grad<bf16_t>(pv[k]);
+        }
+        if (use_drop) {
+          const int gm = ic.m0 + p * RPP + row;
+          const uint64_t grp = ((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2;
+          const float4 m0 = drop.mask4(grp), m1 = drop.mask4(grp + 1);
+          v[0] *= m0.x; v[1] *= m0.y; v[2] *= m0.z; v[3] *= m0.w;
+          v[4] *= m1.x; v[5] *= m1.y; v[6] *= m1.z; v[7] *= m1.w;
+        }
+        if (EK & EK_RES) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += pv[k];
+        }
+        if (do_csum && ok[it]) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) cs[k] += v[k];
+        }
+        uint4 o;
+        o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
+        if (ok[it]) *reinterpret_cast<uint4*>(Cb + off[it]) = o;
+      }
+    }
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                    // E2: the slot may be restaged / refilled
+  }
+  if (EK & EK_GELU_BWD) {                            // uniform across the workgroup (kernel argument)
+    if (e.colsum != nullptr) {
+      float* sp = reinterpret_cast<float*>(smem + SPARE_OFF);
+      if (active) {
+        *reinterpret_cast<f32x4_t*>(sp + r0 * BN + c8 * 8) = f32x4_t{cs[0], cs[1], cs[2], cs[3]};
+        *reinterpret_cast<f32x4_t*>(sp + r0 * BN + c8 * 8 + 4) = f32x4_t{cs[4], cs[5], cs[6], cs[7]};
+      }
+      wait_lds();
+      __builtin_amdgcn_s_barrier();                  // E3
+      if (tid < BN && ic.n0 + tid < g.N) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < RPI; ++k) t += sp[k * BN + tid];
+        atomicAdd(e.colsum + ic.n0 + tid, t);
+      }
+      // the next writer of the spare region is the next tile's fold, >= one step barrier away
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, bool TR, int EK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_ws_kernel(WsArgs g) {
+  typedef Geo<TM, TN> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    Loader<G, TR> ld(g, smem, wg, nwg, wave - 4, lane);
+    ld.issue();
+    const bool second = ld.issue();
+    if (second) wait_vm<G::PW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                                     // B(-1): stage 0 landed
+    unsigned slot = 0;
+    for (int cit = wg; cit < g.nwork; cit += nwg) {
+      const Item ic = item_coord<G>(g, cit);
+      for (int t = 0; t < ic.nk; ++t) {
+        if (ld.issue()) wait_vm<G::PW>(); else wait_vm<0>();          // stage u+2 issued, stage u+1 landed
+        __builtin_amdgcn_s_barrier();                                 // B(u)
+        if (t + 1 < ic.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
+      }
+      if constexpr (!TR) epilogue_rows<G, EK, false>(g, ic, smem, slot, nullptr, wave, lane);
+      slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow0 = wm * TM * 32, brow0 = wn * TN * 32;
+  unsigned ao[TM], bo[TN];                                            // per-lane LDS offsets inside a stage (slice 0)
+  if (!TR) {
+    const int r = lane & 31, kg = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int ra = arow0 + i * 32 + r; ao[i] = ra * 128 + ((kg ^ swz_k(ra)) << 4); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int rb = brow0 + j * 32 + r; bo[j] = G::A_BYTES + rb * 128 + ((kg ^ swz_k(rb)) << 4); }
+  } else {
+    const int p = lane & 15, gq = (lane >> 4) & 1, kg = lane >> 5;
+    const int krow = kg * 8 + (p >> 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int col = arow0 + i * 32 + gq * 16 + 4 * (p & 3);
+      ao[i] = krow * (G::BM * 2) + ((((col >> 3) ^ swz_o<G::BM * 2>(krow)) << 4) | ((col & 7) * 2));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = brow0 + j * 32 + gq * 16 + 4 * (p & 3);
+      bo[j] = G::A_BYTES + krow * (G::BN * 2) + ((((col >> 3) ^ swz_o<G::BN * 2>(krow)) << 4) | ((col & 7) * 2));
+    }
+  }
+  bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
+  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
+    if (!TR) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(st + (ao[i] ^ (ks << 5)));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(st + (bo[j] ^ (ks << 5)));
+    } else {
+      typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const char* q = st + ao[i] + ks * 16 * (G::BM * 2);
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BM * 2)));
+        a[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char* q = st + bo[j] + ks * 16 * (G::BN * 2);
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BN * 2)));
+        b[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  f32x16_t acc[TM][TN];
+  auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!TR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D^T: lane <-> output row
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_barrier();                                       // B(-1)
+  unsigned curo = 0;
+  if (wg < g.nwork) ldf(a0, b0, smem, 0);
+  for (int cit = wg; cit < g.nwork; cit += nwg) {
+    const Item ic = item_coord<G>(g, cit);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool more_items = cit + nwg < g.nwork;
+    unsigned last = curo;
+    for (int t = 0; t < ic.nk; ++t) {
+      const char* cur = smem + curo;
+      last = curo;
+      curo += G::STAGE;
+      if (curo == NS * G::STAGE) curo = 0;
+      const char* nxt = smem + curo;
+      ldf(a1, b1, cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a0, b0, cur, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a1, b1, cur, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds();
+      __builtin_amdgcn_s_barrier();                                   // B(u): done reading `cur`, stage u+1 landed
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ic.nk || (TR && more_items)) ldf(a0, b0, nxt, 0);   // K,K: the next item's first slice is read after the epilogue
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!TR) {
+      __builtin_amdgcn_s_setprio(0);
+      epilogue_rows<G, EK, true>(g, ic, smem, last, acc, wave, lane);
+      __builtin_amdgcn_s_setprio(2);
+      if (more_items) ldf(a0, b0, smem + curo, 0);
+    } else {
+      // fp32 atomics from the accumulator layout: 32 consecutive columns per half-wave, two rows per instruction
+      float* C = static_cast<float*>(g.C);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int gn = ic.n0 + brow0 + j * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int gm = ic.m0 + arow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gm < g.M && gn < g.N) atomicAdd(C + (size_t)gm * g.ldc + gn, acc[i][j][r]);
+          }
+        }
+    }
+  }
+}
+
+// explicit instantiations (hipcc does not emit the host stubs of kernels that are only reached through two
+// levels of host-side templates)
+#define HERO_WS_INST(TM, TN)                                                                  \
+  template __global__ void gemm_ws_kernel<TM, TN, false, 0>(WsArgs);                          \
+  template __global__ void gemm_ws_kernel<TM, TN, false, EK_BIAS>(WsArgs);                    \
+  template __global__ void gemm_ws_kernel<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(WsArgs); \
+  template __global__ void gemm_ws_kernel<TM, TN, false, EK_BIAS | EK_GELU>(WsArgs);          \
+  template __global__ void gemm_ws_kernel<TM, TN, false, EK_RES>(WsArgs);                     \
+  template __global__ void gemm_ws_kernel<TM, TN, false, EK_GELU_BWD>(WsArgs);                \
+  template __global__ void gemm_ws_kernel<TM, TN, true, 0>(WsArgs);
+HERO_WS_INST(3, 3)
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+__global__ void ws_scale_f32_kernel(float* c, int M, int N, int ldc, float beta) {
+  const size_t n4 = (size_t)N >> 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)M * n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / n4, c4 = (i - r * n4) * 4;
+    float4* p = reinterpret_cast<float4*>(c + r * ldc + c4);
+    if (beta == 0.f) {
+      *p = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      float4 v = *p;
+      v.x *= beta; v.y *= beta; v.z *= beta; v.w *= beta;
+      *p = v;
+    }
+  }
+}
+
+static int num_cus() {
+  static int n = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v > 0 ? v : 256;
+  }();
+  return n;
+}
+
+template <int TM, int TN, bool TR, int EK>
+static int launch(WsArgs g, int slot, hipStream_t s) {
+  typedef Geo<TM, TN> G;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws_kernel<TM, TN, TR, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    attr_set = true;
+  }
+  const int grid = g.nwork < num_cus() ? g.nwork : num_cus();
+  void* tok = gemm_prof_begin(slot, s);
+  hipLaunchKernelGGL((gemm_ws_kernel<TM, TN, TR, EK>), dim3(grid), dim3(512), G::LDS, s, g);
+  gemm_prof_end(tok, 2.0 * (double)g.M * (double)g.N * (double)g.K, s);
+  return check_launch("hero_gemm(ws)");
+}
+
+template <int TM, int TN>
+static int launch_kk(const WsArgs& g, hipStream_t s) {
+  const HeroGemmEpilogue& e = g.epi;
+  const bool b = e.bias != nullptr, r = e.residual != nullptr, d = e.dropout.threshold16 != 0;
+  if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, 4, s);
+  if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, 4, s);
+  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, 4, s);
+  if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, 4, s);
+  if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, 4, s);
+  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, 4, s);
+  return -1;
+}
+
+}  // namespace ws
+
+// Problems this family takes: bf16, K,K operands with one of the six hot-path epilogues, or the O,O
+// wgrad accumulate; large enough to fill the chip with 192 x 192 tiles.  force_cfg: -1 heuristic,
+// 8 never, 9 always (when the shape is legal).
+int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_layout,
+                int b_layout, const HeroGemmEpilogue& epi, int force_cfg, hipStream_t s) {
+  using namespace ws;
+  if (force_cfg == 8) return -1;
+  if (force_cfg != 9 && force_cfg != -1) return -1;      // a forced 4-wave geometry
+  typedef Geo<3, 3> G;
+  const bool kk = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
+  const bool oo = a_layout == HERO_LAYOUT_O && b_layout == HERO_LAYOUT_O;
+  if (!kk && !oo) return -1;
+  if (K < 64 || N % 8 != 0 || M < 8) return -1;
+  WsArgs g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.tiles_m = (M + G::BM - 1) / G::BM;
+  g.tiles_n = (N + G::BN - 1) / G::BN;
+  g.epi = epi;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int cus = num_cus();
+  if (kk) {
+    if (K % 64 != 0 || epi.out_f32 || epi.split_k > 1) return -1;
+    if ((size_t)M * lda * 2 >= 0x7fffffffull || (size_t)N * ldb * 2 >= 0x7fffffffull || (size_t)M * ldc >= 0x7fffffffull) return -1;
+    // worth it from about half a round of tiles; below that the 4-wave 64 x 64 / 128 x 128 tiles fill the chip better
+    if (force_cfg != 9 && ntile * 2 < cus) return -1;
+    g.nsplit = 1;
+    g.k_per_split = K;
+    g.nwork = ntile;
+    g.group = N >= 2560 ? 8 : 8;
+    return launch_kk<3, 3>(g, s);
+  }
+  // O,O: fp32 accumulate, reduction split so that the items fill the CUs
+  if (!epi.out_f32 || epi.act != HERO_ACT_NONE || epi.bias || epi.residual || epi.dropout.threshold16 != 0 || epi.colsum) return -1;
+  if (M % 8 != 0) return -1;
+  if ((size_t)K * lda * 2 >= 0xffffffffull || (size_t)K * ldb * 2 >= 0xffffffffull) return -1;
+  const int ksteps = (K + 63) / 64;
+  // The fp32-atomic merge costs ~split x output bytes at ~1.2 TB/s (measured: 31 us for 4 x 9.4 MB) and is paid
+  // after the last k-step by every item at once: worth it only where few splits fill the chip (>= 64 tiles of
+  // 192 x 192, i.e. the 3072 x 768 weights: 77 vs 84 us); smaller outputs stay on the 128 x 128 kernel's finer split.
+  if (force_cfg != 9 && (ksteps < 32 || ntile < 64)) return -1;
+  int split = cus / ntile;                               // at most one round of items
+  if (split > ksteps / 4) split = ksteps / 4;
+  if (split < 1) split = 1;
+  const int per = (ksteps + split - 1) / split;
+  split = (ksteps + per - 1) / per;
+  g.nsplit = split;
+  g.k_per_split = per * 64;
+  g.nwork = ntile * split;
+  g.group = 8;
+  if (epi.beta != 1.f) {
+    hipLaunchKernelGGL(ws_scale_f32_kernel, dim3(1024), dim3(256), 0, s, static_cast<float*>(C), M, N, ldc, epi.beta);
+    const int rc = check_launch("hero_gemm(ws scale)");
+    if (rc) return rc;
+  }
+  return launch<3, 3, true, 0>(g, 7, s);
+}
+
+}  // namespace hero

@@ -445,7 +445,7 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
 
 def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None, seq_off=None):
     """seq_off (int32 [S+1]): packed batch - sequence s is rows [seq_off[s], seq_off[s+1]) of qkv,
-    Lq is the maximum length (<= 64)."""
+    Lq is the maximum length (<= 64; bf16: <= 256)."""
     D = H * 64
     ctx = out if out is not None else torch.empty((qkv.shape[0], D), dtype=qkv.dtype, device=qkv.device)
     probs = torch.empty((S, H, Lq, Lq), dtype=torch.float32, device=qkv.device) if want_probs else None
@@ -455,9 +455,11 @@ def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None, se
     return ctx, probs
 
 
-def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None, out=None, seq_off=None):
+def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None, out=None, seq_off=None, ctx=None):
+    """ctx: the forward output (optional).  With it the bf16 backward of 64 < Lq <= 256 runs on the
+    matrix-core kernels (delta_i = dO_i . ctx_i); without it those lengths take the fp32-VALU path."""
     dqkv = out if out is not None else torch.empty_like(qkv)
-    a = L.Attn(L.ptr(qkv), None, None, L.ptr(probs), L.ptr(dctx), L.ptr(dqkv), S, Lq, H,
+    a = L.Attn(L.ptr(qkv), None, L.ptr(ctx), L.ptr(probs), L.ptr(dctx), L.ptr(dqkv), S, Lq, H,
                1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off))
     L.check(L.lib().hero_attention_bwd(C.byref(a), L.stream()))
     return dqkv
@@ -766,14 +768,14 @@ class SelfAttentionFn(torch.autograd.Function):
         ctx.dims, ctx.drop = (S, Lq, H, D), drop_p
         ctx.params = (wq, bq, wk, bk, wv, bv)
         _use(*ctx.params)
-        ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), qkv, probs)
+        ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), qkv, probs, ctxt)
         return ctxt.view(S, Lq, D)
 
     @staticmethod
     def backward(ctx, dctx):
-        x2, Wqkv_t, qkv, probs = ctx.saved_tensors
+        x2, Wqkv_t, qkv, probs, ctxt = ctx.saved_tensors
         S, Lq, H, D = ctx.dims
-        dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop)
+        dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop, ctx=ctxt)
         dx = k_dgrad_t(dqkv, Wqkv_t).view(S, Lq, D) if ctx.needs_input_grad[0] else None
         _qkv_bwd(dqkv, x2, ctx.params, D)
         return (dx,) + (None,) * 9
@@ -871,11 +873,11 @@ class AttnBlockFn(torch.autograd.Function):
         for seg, p, dr in zip(segs, probs, drops_attn):
             if len(seg) == 4:
                 _, S, Lq, off = seg
-                k_attn_bwd(qkv, p, dctx, S, Lq, H, drop=dr, out=dqkv, seq_off=off)
+                k_attn_bwd(qkv, p, dctx, S, Lq, H, drop=dr, out=dqkv, seq_off=off, ctx=ctxt)
                 continue
             S, Lq = seg
             k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr,
-                       out=dqkv[r0:r0 + S * Lq])
+                       out=dqkv[r0:r0 + S * Lq], ctx=ctxt[r0:r0 + S * Lq])
             r0 += S * Lq
         _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
         dx = k_dgrad_t(dqkv, Wqkv_t, residual=dy1).view(xshape)    # + residual-path gradient, fused

@@ -244,11 +244,11 @@ class BertEncoder(nn.Module):
     allow_packing = True    # global switch (tests compare against the padded formulation)
 
     @staticmethod
-    def _pack_plan(mask_list, lens):
+    def _pack_plan(mask_list, lens, max_len=64):
         """Row maps between the padded layout (groups stacked, row = position) and the packed one
         (masked positions removed, sequences back to back).  None when (almost) every position is
         valid.  One small device->host read per distinct batch; cached on the mask tensors."""
-        key = tuple((m.data_ptr(), m._version, tuple(m.shape)) for m in mask_list)
+        key = tuple((m.data_ptr(), m._version, tuple(m.shape)) for m in mask_list) + (max_len,)
         hit = BertEncoder._PLANS.get(key)
         if hit is not None:
             return hit[0]
@@ -259,7 +259,7 @@ class BertEncoder(nn.Module):
         plan = None
         counts = torch.cat([(m != 0).sum(1).reshape(-1) for m in mask_list]).cpu()
         lmax = int(counts.max()) if counts.numel() else 0
-        if 0 < valid < 0.9 * total and lmax <= 64:
+        if 0 < valid < 0.9 * total and lmax <= max_len:    # the variable-length attention kernels' limit
             gather = torch.nonzero(flat, as_tuple=False).reshape(-1).to(torch.int32)
             inverse = torch.full((total,), -1, dtype=torch.int32)
             inverse[gather.long()] = torch.arange(valid, dtype=torch.int32)
@@ -295,7 +295,8 @@ class BertEncoder(nn.Module):
         x = torch.cat([t.reshape(-1, D) for t in xs], 0) if len(xs) > 1 else xs[0].reshape(-1, D)
         plan = None
         if self.pack_ragged and BertEncoder.allow_packing and all(m is not None for m in mask_list) and x.is_cuda:
-            plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs])
+            plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs],
+                                   max_len=256 if cd == torch.bfloat16 else 64)
         if plan is not None:
             gather, inverse, inv, back, off, n_seq, lmax = plan
             x = HF.PermuteRowsFn.apply(x.contiguous(), gather, inverse)

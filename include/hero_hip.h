@@ -152,7 +152,8 @@ int hero_colsum(const void* x, float* out, int rows, int cols, int ld, int dtype
 typedef struct HeroAttn {
   const void* qkv;    /* [S*L, 3*H*64] dtype                                                   */
   const float* mask;  /* [S, L] additive fp32 ((1-m)*-10000, model/layers.py:299-302) or NULL   */
-  void* ctx;          /* fwd out [S*L, H*64] dtype                                              */
+  void* ctx;          /* fwd out [S*L, H*64] dtype; bwd in (optional): with it the bf16 backward of    */
+                      /* 64 < L <= 256 runs on the matrix cores (delta_i = dO_i . ctx_i)               */
   float* probs;       /* [S, H, L, L] fp32 softmax output (pre-dropout); fwd out (may be NULL   */
                       /* for inference), bwd in                                                 */
   const void* dctx;   /* bwd in  [S*L, H*64] dtype                                              */
@@ -161,7 +162,7 @@ typedef struct HeroAttn {
   float scale;        /* 1/sqrt(64)                                                             */
   int dtype;
   HeroDropout dropout; /* on P; index = ((s*H+h)*L + q)*round_up(L,4) + k                       */
-  const int32_t* seq_off; /* optional [S+1] row offsets of a PACKED batch (L <= 64): sequence s is   */
+  const int32_t* seq_off; /* optional [S+1] row offsets of a PACKED batch (L <= 64; bf16: 256): sequence s is */
                        /* rows [seq_off[s], seq_off[s+1]) of qkv/ctx/dctx/dqkv, at most L long;   */
                        /* probs keeps its [S, H, L, L] layout, dropout indices use L; mask NULL   */
 } HeroAttn;

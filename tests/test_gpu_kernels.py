@@ -106,6 +106,70 @@ def test_gemm_forced_geometries(HF, Lb, cfg):
     close(dx, (dy.float() @ w.float()) * gp, dtype, scale=math.sqrt(N) * 0.05 * 2)
 
 
+@pytest.mark.parametrize("M,N,K", [(12000, 768, 768), (12000, 2304, 768), (12000, 768, 3072), (1000, 200, 128),
+                                   (385, 192, 64), (24000, 3072, 768)])
+def test_gemm_wave_specialised_matches_4wave_kernels(HF, Lb, M, N, K):
+    """gemm_ws.hip (persistent 192x192 tiles, loader / compute waves) against the 4-wave kernels and the fp32
+    reference: the six fused epilogues, the SAME dropout mask (index m*N + n), row / column tails, several
+    tiles per workgroup (24000 x 3072: 2000 tiles on 256 CUs)."""
+    dtype = torch.bfloat16
+    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
+    res, u = rnd(M, N, dtype=dtype, seed=4), rnd(M, N, dtype=dtype, seed=6)
+    drop = HF.RNG.make(0.1, True, x.device)
+    cs = [rnd(N, seed=7), None]
+    cs[1] = cs[0].clone()
+
+    def run(cfg, k):
+        Lb.lib().hero_gemm_force_config(cfg)
+        try:
+            aux = torch.empty((M, N), dtype=dtype, device=x.device)
+            return [HF.k_linear(x, w, b),
+                    HF.k_linear(x, w, b, residual=res, drop=drop),
+                    HF.k_linear(x, w, b, act=Lb.ACT_GELU, aux=aux), aux,
+                    HF.k_linear(x, w),
+                    HF.k_linear(x, w, residual=res),
+                    HF.k_dgrad_t(x, w, act=Lb.ACT_GELU_BWD, aux=u, colsum=cs[k])]
+        finally:
+            Lb.lib().hero_gemm_force_config(-1)
+
+    got, old = run(9, 0), run(8, 1)
+    ref = x.float() @ w.float().t()
+    sc = math.sqrt(K) * 0.05
+    close(got[0], ref + b, dtype, scale=sc)
+    close(got[4], ref, dtype, scale=sc)
+    close(got[5], ref + res.float(), dtype, scale=sc + 1)
+    close(got[3], ref + b, dtype, scale=sc)
+    close(got[2], torch.nn.functional.gelu(ref + b), dtype, scale=sc)
+    for a_, b_ in zip(got, old):                      # same inputs, same mask: equal up to bf16 rounding of the output
+        close(a_, b_, dtype, scale=sc + 1)
+    kept = (got[1].float() - res.float()).abs() > 1e-6   # dropout zeroes the same elements in both families
+    kept_old = (old[1].float() - res.float()).abs() > 1e-6
+    assert (kept != kept_old).float().mean().item() < 1e-3
+    torch.testing.assert_close(cs[0], cs[1], rtol=2e-2, atol=0.05 * math.sqrt(M))
+
+
+@pytest.mark.parametrize("rows,n_out,n_in", [(12000, 768, 768), (12040, 3072, 768), (4100, 768, 3072), (520, 200, 136),
+                                             (12000, 2304, 768)])
+def test_gemm_wave_specialised_wgrad(HF, Lb, rows, n_out, n_in):
+    """dW += dY^T X on the wave-specialised O,O kernel: transpose reads, reduction split with fp32
+    atomics, reduction tails (rows % 64 != 0 -> out-of-range rows read as zeros), accumulate into C."""
+    dtype = torch.bfloat16
+    dy, x = rnd(rows, n_out, dtype=dtype, seed=1), rnd(rows, n_in, dtype=dtype, seed=2)
+    ref = dy.float().t() @ x.float()
+    Lb.lib().hero_gemm_force_config(9)
+    try:
+        dW = HF.k_wgrad(dy, x)
+        acc = torch.ones(n_out, n_in, device=x.device)
+        HF.k_wgrad(dy, x, out=acc, beta=1.0)
+        half = HF.k_wgrad(dy, x, col0=n_out // 2 // 8 * 8, ncols=n_out - n_out // 2 // 8 * 8)
+    finally:
+        Lb.lib().hero_gemm_force_config(-1)
+    tol = dict(rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    torch.testing.assert_close(dW, ref, **tol)
+    torch.testing.assert_close(acc, ref + 1.0, **tol)
+    torch.testing.assert_close(half, ref[n_out // 2 // 8 * 8:], **tol)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(700, 776, 768), (12000, 3072, 768), (130, 64, 64)])
 def test_gemm_output_column_sums(HF, Lb, dtype, M, N, K):
@@ -173,7 +237,8 @@ def test_layernorm_fp32_in_bf16_out_and_tables(HF):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("S,L,H", [(3, 9, 2), (5, 24, 12), (2, 60, 12), (2, 100, 3), (1, 130, 2), (4, 15, 12),
-                                   (3, 32, 4), (2, 33, 2), (2, 64, 3), (41, 24, 12), (1, 1, 1)])
+                                   (3, 32, 4), (2, 33, 2), (2, 64, 3), (41, 24, 12), (1, 1, 1), (2, 65, 2),
+                                   (3, 128, 2), (2, 129, 3), (2, 200, 4), (3, 256, 12)])
 def test_attention_fwd_bwd(HF, dtype, S, L, H):
     D = H * 64
     qkv = rnd(S * L, 3 * D, dtype=dtype, seed=1)
@@ -194,33 +259,38 @@ def test_attention_fwd_bwd(HF, dtype, S, L, H):
     torch.testing.assert_close(probs, pr, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-3)
     close(ctx, ref, dtype)
     ref.backward(dctx.float())
-    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, L, H)
+    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, L, H, ctx=ctx)     # ctx: 64 < L <= 256 in bf16 runs on the matrix cores
     close(dqkv, q.grad, dtype, scale=2)
+    if dtype == torch.bfloat16 and L > 64:                        # ... and agrees with the fp32-VALU kernels (no ctx)
+        close(dqkv, HF.k_attn_bwd(qkv, probs, dctx, S, L, H), dtype, scale=2)
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("lens,H", [([24, 9, 1, 17, 24], 3), ([60, 33, 5], 2), ([15, 15], 12), ([7], 1)])
+@pytest.mark.parametrize("lens,H", [([24, 9, 1, 17, 24], 3), ([60, 33, 5], 2), ([15, 15], 12), ([7], 1),
+                                    ([100, 37, 64, 1], 2), ([256, 130, 31], 3)])
 def test_attention_packed_sequences(HF, dtype, lens, H):
     """Variable-length (packed) batches: sequence s = rows [off[s], off[s+1]) - same result as running
     every sequence on its own, forward and backward, with and without dropout (self-consistent)."""
+    if dtype == torch.float32 and max(lens) > 64:
+        pytest.skip("packed batches beyond 64 rows exist in the bf16 matrix-core kernels only")
     D = H * 64
     S, Lmax, M = len(lens), max(lens), sum(lens)
     off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32).cuda()
     qkv = rnd(M, 3 * D, dtype=dtype, seed=1)
     dctx = rnd(M, D, dtype=dtype, seed=2)
     ctx, probs = HF.k_attn_fwd(qkv, None, S, Lmax, H, seq_off=off)
-    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, Lmax, H, seq_off=off)
+    dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, Lmax, H, seq_off=off, ctx=ctx)
     r0 = 0
     for s_, n in enumerate(lens):
         c1, p1 = HF.k_attn_fwd(qkv[r0:r0 + n].contiguous(), None, 1, n, H)
-        d1 = HF.k_attn_bwd(qkv[r0:r0 + n].contiguous(), p1, dctx[r0:r0 + n].contiguous(), 1, n, H)
+        d1 = HF.k_attn_bwd(qkv[r0:r0 + n].contiguous(), p1, dctx[r0:r0 + n].contiguous(), 1, n, H, ctx=c1)
         close(ctx[r0:r0 + n], c1, dtype)
         torch.testing.assert_close(probs[s_, :, :n, :n], p1[0], rtol=1e-5, atol=1e-6)
         close(dqkv[r0:r0 + n], d1, dtype, scale=2)
         r0 += n
     drop = HF.RNG.make(0.2, True, qkv.device)
     cd, pd = HF.k_attn_fwd(qkv, None, S, Lmax, H, drop=drop, seq_off=off)
-    dd = HF.k_attn_bwd(qkv, pd, dctx, S, Lmax, H, drop=drop, seq_off=off)
+    dd = HF.k_attn_bwd(qkv, pd, dctx, S, Lmax, H, drop=drop, seq_off=off, ctx=cd)
     lhs = (dctx.float() * cd.float()).sum()
     rhs = (dd[:, 2 * D:].float() * qkv[:, 2 * D:].float()).sum()
     torch.testing.assert_close(lhs, rhs, rtol=2e-2 if dtype == torch.bfloat16 else 1e-3, atol=0.5 if dtype == torch.bfloat16 else 1e-2)
@@ -254,9 +324,9 @@ def test_attention_dropout_adjoint(HF, Lb):
     assert len(vals) == 2 and abs(vals.max().item() - 1 / 0.9) < 1e-5
 
 
-@pytest.mark.parametrize("S,L,H", [(5, 24, 3), (3, 15, 2), (2, 60, 2), (2, 37, 1)])
+@pytest.mark.parametrize("S,L,H", [(5, 24, 3), (3, 15, 2), (2, 60, 2), (2, 37, 1), (2, 100, 2), (2, 200, 3), (1, 256, 2)])
 def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
-    """The bf16 matrix-core attention kernels (L <= 64) and the fp32 VALU kernels draw the SAME dropout
+    """The bf16 matrix-core attention kernels (L <= 64 and 64 < L <= 256) and the fp32 VALU kernels draw the SAME dropout
     mask for the same site (index = ((s*H+h)*L + q)*round_up(L,4) + k): forward and backward agree on
     bf16-representable inputs within the bf16 tolerance, and the adjoint identity holds."""
     D = H * 64
@@ -270,7 +340,7 @@ def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
     ctx32, probs32 = HF.k_attn_fwd(qkv16.float(), madd, S, L, H, drop=drop)
     torch.testing.assert_close(probs16, probs32, rtol=2e-2, atol=2e-3)
     close(ctx16, ctx32, torch.bfloat16)
-    d16 = HF.k_attn_bwd(qkv16, probs32, dctx16, S, L, H, drop=drop)
+    d16 = HF.k_attn_bwd(qkv16, probs32, dctx16, S, L, H, drop=drop, ctx=ctx16)
     d32 = HF.k_attn_bwd(qkv16.float(), probs32, dctx16.float(), S, L, H, drop=drop)
     close(d16, d32, torch.bfloat16, scale=2)
     lhs = (dctx16.float() * ctx16.float()).sum()

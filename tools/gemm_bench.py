@@ -16,8 +16,8 @@ def timeit(fn, n=20, warm=3):
 
 def main():
     dt = torch.bfloat16
-    shapes = [(11520, 3072, 768), (11520, 768, 3072), (11520, 768, 768), (11520, 2304, 768),
-              (11520, 768, 64), (11520, 768, 1536), (1920, 768, 768), (480, 768, 768), (1920, 768, 4352)]
+    shapes = [(12000, 3072, 768), (12000, 768, 3072), (12000, 768, 768), (12000, 2304, 768),
+              (12000, 768, 2304), (1920, 768, 768), (1920, 3072, 768), (1920, 768, 4352)]
     only = sys.argv[1] if len(sys.argv) > 1 else "all"
     cfg = int(sys.argv[2]) if len(sys.argv) > 2 else -1
     L.lib().hero_gemm_force_config(cfg)

@@ -23,6 +23,7 @@ EXPORTS = [
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
     "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
+    "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
 ]
 
 
@@ -35,6 +36,12 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
                 ("act", C.c_int), ("out_f32", C.c_int), ("beta", C.c_float),
                 ("split_k", C.c_int), ("dropout", Dropout), ("colsum", C.c_void_p)]
+
+
+class CrossEntropy(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("labels", C.c_void_p), ("loss", C.c_void_p), ("lse", C.c_void_p),
+                ("dloss", C.c_void_p), ("dlogits", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
+                ("ld", C.c_int), ("dtype", C.c_int), ("inv_temp", C.c_float), ("ignore_index", C.c_int64)]
 
 
 class LnFwd(C.Structure):
@@ -178,6 +185,8 @@ def lib():
                        ("hero_score_max_fwd", ScoreMax), ("hero_score_max_bwd", ScoreMax),
                        ("hero_rank_loss", RankLoss), ("hero_st_ed_fwd", StEd), ("hero_st_ed_bwd", StEd)):
             getattr(L, fn).argtypes = [C.POINTER(st), C.c_void_p]
+        L.hero_cross_entropy_fwd.argtypes = [C.POINTER(CrossEntropy), C.c_void_p]
+        L.hero_cross_entropy_bwd.argtypes = [C.POINTER(CrossEntropy), C.c_void_p]
         _lib = L
     return _lib
 

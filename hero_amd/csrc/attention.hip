@@ -100,11 +100,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
   const int Lp = (L + 3) & ~3;
   T* Ks = reinterpret_cast<T*>(smem);
   T* Vs = Ks + (size_t)L * STR;
-  T* Qs = Vs + (size_t)L * STR;
-  float* Ps = reinterpret_cast<float*>(smem + (((size_t)(2 * L * STR + L * DH) * sizeof(T)) + 15) / 16 * 16) + wave * Lp;
+  float* Ps = reinterpret_cast<float*>(smem + (((size_t)(2 * L * STR) * sizeof(T)) + 15) / 16 * 16) + wave * Lp;
 
   const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D;
-  stage_head<T>(qkv + h * DH, 3 * D, L, Qs, DH);
+  const T* Qg = qkv + h * DH;                  // a query row is read once, by one wave: no LDS copy
   stage_head<T>(qkv + D + h * DH, 3 * D, L, Ks, STR);
   stage_head<T>(qkv + 2 * D + h * DH, 3 * D, L, Vs, STR);
   __syncthreads();
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
 
   for (int i = wave; i < L; i += 4) {
     float qv[DPL];
-    lds_row_slice<T, DPL>(Qs + i * DH, p, qv);
+    lds_row_slice<T, DPL>(Qg + (size_t)i * 3 * D, p, qv);
     // ---- scores
     float mx = -3.0e38f;
     for (int j0 = 0; j0 < L; j0 += KPP) {
@@ -506,7 +505,7 @@ constexpr size_t LDS_BUDGET = 150 * 1024;
 
 template <typename T> static size_t fwd_lds(int L) {
   const int Lp = (L + 3) & ~3;
-  return (((size_t)(2 * L * KvLay<T>::STRIDE + L * DH) * sizeof(T)) + 15) / 16 * 16 + (size_t)4 * Lp * sizeof(float);
+  return (((size_t)(2 * L * KvLay<T>::STRIDE) * sizeof(T)) + 15) / 16 * 16 + (size_t)4 * Lp * sizeof(float);
 }
 template <typename T> static size_t bwd_lds_fixed(int L) {
   return (((size_t)(2 * L * KvLay<T>::STRIDE + 2 * L * DH) * sizeof(T)) + 15) / 16 * 16;
@@ -615,5 +614,6 @@ extern "C" int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream) {
   return a->dtype == HERO_BF16 ? run<bf16_t>(*a, true, s) : run<float>(*a, true, s);
 }
 extern "C" int hero_attention_max_len(int dtype, int backward) {
+  if (dtype == HERO_BF16 && use_mfma()) return 256;       // matrix-core kernels (the backward wants a.ctx beyond 64)
   return dtype == HERO_BF16 ? max_len<bf16_t>(backward) : max_len<float>(backward);
 }

@@ -586,7 +586,10 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
   const int ksteps = (K + 63) / 64;
   // The fp32-atomic merge costs ~split x output bytes at ~1.2 TB/s (measured: 31 us for 4 x 9.4 MB) and is paid
   // after the last k-step by every item at once: worth it only where few splits fill the chip (>= 64 tiles of
-  // 192 x 192, i.e. the 3072 x 768 weights: 77 vs 84 us); smaller outputs stay on the 128 x 128 kernel's finer split.
+  // 192 x 192, i.e. the 3072 x 768 weights: 77 vs 84 us); smaller outputs stay on the 128 x 128 kernel's finer
+  // split.  (Tried and dropped: 96 x 96 tiles with the reduction split across the four compute waves of a
+  // workgroup and no cross-workgroup merge - 104 vs 82 us: four times the LDS-DMA bytes per flop, and the
+  // direct-to-LDS path of a CU saturates near 50 GB/s while MFMAs and fragment reads are running.)
   if (force_cfg != 9 && (ksteps < 32 || ntile < 64)) return -1;
   int split = cus / ntile;                               // at most one round of items
   if (split > ksteps / 4) split = ksteps / 4;

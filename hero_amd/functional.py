@@ -598,6 +598,65 @@ def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None):
     return LinearFn.apply(x, weight, bias, act, residual)
 
 
+class MatmulNTFn(torch.autograd.Function):
+    """y = a @ b^T for two ACTIVATION tensors in the compute dtype (no weight cache): the MFM-NCE logits
+    masked_output @ [pos; neg]^T (model/model.py:271-291).  b's rows are padded to a multiple of 8 by the caller."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2, b2 = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a2, b2)
+        return k_linear(a2, b2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, b2 = ctx.saved_tensors
+        dy2 = dy.contiguous()
+        da = k_dgrad(dy2, b2) if ctx.needs_input_grad[0] else None
+        db = k_wgrad(dy2, a2).to(b2.dtype) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def matmul_nt(a, b):
+    return MatmulNTFn.apply(a, b)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Per-row softmax cross-entropy of [rows, ld] logits over their first `ncols` columns (hero_cross_entropy_*);
+    reduction 'none', rows labelled `ignore_index` give 0."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ncols, ignore_index, inv_temp):
+        x2 = logits.contiguous()
+        rows, ld = x2.shape
+        lab = labels.contiguous().to(torch.int64)
+        loss = torch.empty((rows,), dtype=torch.float32, device=x2.device)
+        lse = torch.empty((rows,), dtype=torch.float32, device=x2.device)
+        a = L.CrossEntropy(L.ptr(x2), L.ptr(lab), L.ptr(loss), L.ptr(lse), None, None, rows, ncols, ld, L.dt(x2),
+                           inv_temp, ignore_index)
+        L.check(L.lib().hero_cross_entropy_fwd(C.byref(a), L.stream()))
+        ctx.save_for_backward(x2, lab, lse)
+        ctx.meta = (ncols, ignore_index, inv_temp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x2, lab, lse = ctx.saved_tensors
+        ncols, ignore_index, inv_temp = ctx.meta
+        rows, ld = x2.shape
+        g = dloss.contiguous().float()
+        dx = torch.empty_like(x2)
+        a = L.CrossEntropy(L.ptr(x2), L.ptr(lab), None, L.ptr(lse), L.ptr(g), L.ptr(dx), rows, ncols, ld, L.dt(x2),
+                           inv_temp, ignore_index)
+        L.check(L.lib().hero_cross_entropy_bwd(C.byref(a), L.stream()))
+        return dx, None, None, None, None
+
+
+def cross_entropy(logits, labels, ncols=None, ignore_index=-100, inv_temp=1.0):
+    return CrossEntropyFn.apply(logits, labels, logits.shape[1] if ncols is None else ncols, ignore_index,
+                                float(inv_temp))
+
+
 class EmbedLnFn(torch.autograd.Function):
     """y = dropout(LN(x + sum_k table_k[idx_k])) — embedding sums of model/embed.py fused with their
     LayerNorm.  idx_k None = row 0 of the given (fp32) table slice for every row.  Gradients of

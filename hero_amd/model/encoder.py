@@ -198,11 +198,12 @@ class CrossModalTrm(RobertaPreTrainedModel):
         seq = self.encoder(emb, attention_mask)[0]
         rows = torch.nonzero(txt_mask_tgt.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32)
         masked = HF.GatherRowsFn.apply(seq.reshape(-1, seq.shape[-1]), None, rows.contiguous())
+        if compute_loss:      # fused log-softmax + NLL over the vocabulary GEMM output, padding columns excluded
+            logits = self.lm_head(masked, raw=True)
+            return HF.cross_entropy(logits, txt_labels, ncols=logits.shape[1] - self.vocab_pad)
         scores = self.lm_head(masked)
         if self.vocab_pad:
             scores = scores[:, :-self.vocab_pad]
-        if compute_loss:
-            return F.cross_entropy(scores, txt_labels, reduction="none")
         return scores
 
 

@@ -326,8 +326,10 @@ class BertLMPredictionHead(nn.Module):
         self.decoder.weight = bert_model_embedding_weights
         self.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, raw=False):
+        """raw: the logits in the compute dtype (input of the fused cross-entropy) instead of an fp32 copy."""
         x = HF.cast(hidden_states, HF.compute_dtype())
         h = HF.linear(x, self.dense.weight, self.dense.bias, act=L.ACT_GELU)
         h = self.LayerNorm(h)
-        return HF.cast(HF.linear(h, self.decoder.weight, self.bias), torch.float32)
+        logits = HF.linear(h, self.decoder.weight, self.bias)
+        return logits if raw else HF.cast(logits, torch.float32)

@@ -202,11 +202,16 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         return self.mfm_nce(pred, targets, neg)
 
     def mfm_nce(self, masked_output, pos_output, neg_output, compute_loss=True):
-        logits = torch.cat([masked_output @ pos_output.t(), masked_output @ neg_output.t()], 1).float()
+        cd = HF.compute_dtype()
+        cand = torch.cat([pos_output, neg_output], 0)
+        n = cand.shape[0]
+        if n % 8:                                               # GEMM column granularity; the loss ignores the padding
+            cand = torch.cat([cand, cand.new_zeros(8 - n % 8, cand.shape[1])], 0)
+        logits = HF.matmul_nt(HF.cast(masked_output, cd), HF.cast(cand, cd))      # [n_masked, n_masked + n_neg (+pad)]
         if not compute_loss:
-            return logits
+            return logits[:, :n].float()
         tgt = torch.arange(masked_output.size(0), device=logits.device)
-        return F.cross_entropy(logits / self.nce_temp, tgt, reduction="none")
+        return HF.cross_entropy(logits, tgt, ncols=n, inv_temp=1.0 / self.nce_temp)
 
     def forward_fom(self, batch, compute_loss=True):
         order = batch["shuffled_orders"]
@@ -221,9 +226,10 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         enc = self.c_encoder(clip_level_frame_feat=shuffled, clip_level_pos_ids=None,
                              attention_mask=batch["c_attn_masks"])
         logits = HF.cast(self.fom_output(enc.reshape(B * Lc, D)), torch.float32)
-        if compute_loss:
-            return F.cross_entropy(logits, batch["targets"].view(-1), ignore_index=-1,
-                                   reduction="mean")
+        if compute_loss:                                        # mean over the rows that carry a target
+            tgt = batch["targets"].reshape(-1)
+            rows = HF.cross_entropy(logits, tgt, ignore_index=-1)
+            return rows.sum() / (tgt != -1).sum().clamp(min=1)
         return logits
 
     def initialize(self):

@@ -387,6 +387,29 @@ typedef struct HeroStEd {
 int hero_st_ed_fwd(const HeroStEd* a, hero_stream_t stream);
 int hero_st_ed_bwd(const HeroStEd* a, hero_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Softmax cross-entropy over wide logit rows (pre-training heads, BASELINE configs[3]):        */
+/*   MLM  model/encoder.py:355-389, model/layers.py:330-354 (vocabulary GEMM output; `cols`     */
+/*        excludes the vocabulary padding of model/encoder.py:232-233, ld includes it)          */
+/*   MFM-NCE model/model.py:271-291 (logits / nce_temp)   FOM model/model.py:293-336            */
+/* x = logits * inv_temp;  loss[r] = lse(x[r, :cols]) - x[r, labels[r]]  (0 when labels[r] ==   */
+/* ignore_index);  dlogits[r, c] = (softmax(x[r])[c] - [c == labels[r]]) * dloss[r] * inv_temp, */
+/* zero rows for ignored labels, zero in columns >= cols.  dlogits may alias logits.            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct HeroCrossEntropy {
+  const void* logits;    /* [rows, ld] dtype                                                    */
+  const int64_t* labels; /* [rows]                                                              */
+  float* loss;           /* fwd out [rows]                                                      */
+  float* lse;            /* fwd out / bwd in [rows]: log-sum-exp of x[r, :cols]                 */
+  const float* dloss;    /* bwd in [rows]                                                       */
+  void* dlogits;         /* bwd out [rows, ld] dtype                                            */
+  int rows, cols, ld, dtype;
+  float inv_temp;
+  int64_t ignore_index;
+} HeroCrossEntropy;
+int hero_cross_entropy_fwd(const HeroCrossEntropy* a, hero_stream_t stream);
+int hero_cross_entropy_bwd(const HeroCrossEntropy* a, hero_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

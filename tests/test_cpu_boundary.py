@@ -42,7 +42,7 @@ def test_struct_layouts_match_header_sizes(built_lib):
     src = '#include <stdio.h>\n#include "hero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(HeroDropout),sizeof(HeroGemmEpilogue),sizeof(HeroLnFwd),sizeof(HeroLnBwd),' \
           'sizeof(HeroAttn),sizeof(HeroAdamW));printf("%zu %zu %zu\\n",sizeof(HeroTensorDesc),' \
-          'sizeof(HeroAdamWGroup),sizeof(HeroAdamWMulti));return 0;}\n'
+          'sizeof(HeroAdamWGroup),sizeof(HeroAdamWMulti));printf("%zu\\n",sizeof(HeroCrossEntropy));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "s.c"), "w") as f:
             f.write(src)
@@ -51,7 +51,7 @@ def test_struct_layouts_match_header_sizes(built_lib):
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
     mine = [ctypes.sizeof(c) for c in (_lib.Dropout, _lib.GemmEpilogue, _lib.LnFwd, _lib.LnBwd,
                                        _lib.Attn, _lib.AdamW, _lib.TensorDesc, _lib.AdamWGroup,
-                                       _lib.AdamWMulti)]
+                                       _lib.AdamWMulti, _lib.CrossEntropy)]
     assert mine == sizes
 
 

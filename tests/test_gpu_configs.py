@@ -1,0 +1,243 @@
+"""BASELINE.json configurations at (or near) full size on a real MI355X, through the C ABI, against the
+CPU oracle (oracle == reference: tests/test_oracle_golden.py):
+
+  * configs[1]: HERO-base, bf16, the FULL D2 batch the bench runs (32 videos: the benched kernels -
+    wave-specialised 192x192 GEMMs, matrix-core attention, fused LayerNorm - are the ones under test):
+    forward, the three VSM losses and a handful of gradients, with the bf16 tolerance stated below;
+  * configs[4] shapes: 256-frame Temporal Transformer (64 subtitles x 4 frames per video), regular and ragged,
+    fp32 forward against the oracle, bf16 against fp32, bf16 gradients against the oracle's;
+  * the hipGraph regression of round 1 (7a0be53): >= 300 replayed steps with a device-wide synchronise in
+    the middle must converge like the eager run.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import hero_oracle as O
+from tests.util import GOLDEN, load_tiny, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+# bf16 storage (2^-9 relative per rounding) through 9 post-LN layers; measured 1-2e-2 on HERO-base
+BF16_MAX_TOL = 6e-2      # max |a-b| / max |b| under the mask (same metric as test_gpu_parity)
+BF16_L2_TOL = 3e-2       # ||a-b||_2 / ||b||_2 under the mask: an element-weighted relative error
+FP32_TOL = 5e-4          # north_star: 1e-3 relative fp32
+
+HERO_BASE = {
+    "f_config": dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.1,
+                     hidden_size=768, initializer_range=0.02, intermediate_size=3072,
+                     max_position_embeddings=514, num_attention_heads=12, num_hidden_layers=6,
+                     type_vocab_size=2, vocab_size=2048),
+    "c_config": dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.1,
+                     hidden_size=768, initializer_range=0.02, intermediate_size=3072,
+                     max_position_embeddings=514, num_attention_heads=12, num_hidden_layers=3,
+                     type_vocab_size=2),
+    "q_config": dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.1,
+                     hidden_size=768, initializer_range=0.02, intermediate_size=3072,
+                     num_attention_heads=12, max_position_embeddings=514, num_hidden_layers=0,
+                     type_vocab_size=1, vocab_size=2048)}
+
+
+def l2_err(a, b, mask=None):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if mask is not None:
+        m = mask.bool().cpu()
+        a, b = a[m], b[m]
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def hero_base(seed=0):
+    """HERO-base with a 2048-word vocabulary (the embedding table is a lookup, not on the GEMM path) and
+    non-trivial LayerNorm / bias parameters; returns (cpu state dict, cuda model in train mode, p = 0)."""
+    from hero_amd.model import HeroForVcmr
+    from hero_amd.utils.misc import set_dropout
+    path = "/tmp/hero_base_small_vocab_cfg.json"
+    with open(path, "w") as f:
+        json.dump(HERO_BASE, f)
+    torch.manual_seed(seed)
+    model = HeroForVcmr.from_pretrained(path, {}, vfeat_dim=4352, max_frm_seq_len=100, lw_neg_ctx=8.0,
+                                        lw_neg_q=8.0, lw_st_ed=0.01, ranking_loss_type="hinge",
+                                        use_hard_negative=False, hard_pool_size=20, margin=0.1,
+                                        use_all_neg=True, drop_svmr_prob=0.0)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    set_dropout(model, 0.0)
+    return P, model
+
+
+GRAD_NAMES = ["v_encoder.f_encoder.encoder.layer.0.attention.self.query.weight",
+              "v_encoder.f_encoder.encoder.layer.5.intermediate.dense.weight",
+              "v_encoder.f_encoder.encoder.layer.2.output.dense.bias",
+              "v_encoder.f_encoder.encoder.layer.3.attention.output.LayerNorm.weight",
+              "v_encoder.f_encoder.img_embeddings.img_linear.weight",
+              "v_encoder.c_encoder.encoder.layer.1.attention.self.value.weight",
+              "v_encoder.c_encoder.encoder.layer.2.output.dense.weight",
+              "v_encoder.frame_transform.net.1.weight",
+              "video_query_linear.weight"]
+
+
+def probe(shape, mask, seed=21):
+    """Fixed random weights for the smooth part of the gradient objective (zero at padded frames)."""
+    R = torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+    return R * mask.unsqueeze(-1).float()
+
+
+def objective(l_st_ed, frames, R):
+    """J = start/end cross-entropy (through queries, both encoders and the head) + <frames, R> / #frames.
+    The ranking losses are left out of the GRADIENT check on purpose: max(0, margin + s_neg - s_pos) has a
+    gradient that jumps with the sign of its argument, and at random initialisation most of the B x B score
+    differences sit within bf16 noise of the margin (measured: 35 % gradient difference at 2e-4 loss
+    difference).  Their VALUES are checked."""
+    return l_st_ed.mean() + (frames.float() * R.to(frames.device)).sum() / R.shape[0] / R.shape[1]
+
+
+def oracle_losses_and_grads(batch, P, names):
+    cfg = O.cfg_from_json(HERO_BASE)
+    Pq = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("pad")) for k, v in P.items()}
+    losses = O.vsm_losses(batch, Pq, cfg)
+    frames = O.forward_repr(batch, Pq, cfg)
+    R = probe(frames.shape, batch["c_attn_masks"])
+    objective(losses[0], frames, R).backward()
+    return [l.detach() for l in losses], {n: Pq[n].grad for n in names}, frames.detach(), R
+
+
+def hip_report(model, b, batch, ref_frames_for_fwd, ref_losses, ref_grads, R, names):
+    with torch.no_grad():
+        frames = model.v_encoder(b, "repr")
+    report = {"repr.max": rel_err(frames, ref_frames_for_fwd, batch["c_attn_masks"]),
+              "repr.l2": l2_err(frames, ref_frames_for_fwd, batch["c_attn_masks"])}
+    losses = model(b, task="tvr", compute_loss=True)
+    for k, got, want in zip(("st_ed", "neg_ctx", "neg_q"), losses, ref_losses):
+        report["loss." + k] = abs(float(got.detach()) - float(want)) / (abs(float(want)) + 1e-4)
+    objective(losses[0], model.v_encoder(b, "repr"), R).backward()
+    params = dict(model.named_parameters())
+    for n in names:
+        report["grad." + n] = l2_err(params[n].grad, ref_grads[n])
+    print(json.dumps(report, indent=1))
+    return report
+
+
+def test_hero_base_bf16_full_d2_batch_vs_oracle():
+    """configs[1] at the size the bench runs, in the dtype the bench runs."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.synth import make_batch
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.set_grad_sink(None)
+    P, model = hero_base()
+    batch = make_batch("D2", vocab=2048, seed=7)
+    ref_losses, ref_grads, ref_frames, R = oracle_losses_and_grads(batch, P, GRAD_NAMES)
+    b = to_dev(batch, "cuda")
+    report = hip_report(model, b, batch, ref_frames, ref_losses, ref_grads, R, GRAD_NAMES)
+    assert report["repr.max"] < BF16_MAX_TOL and report["repr.l2"] < BF16_L2_TOL, report
+    assert all(v < 2e-2 for k, v in report.items() if k.startswith("loss.")), report
+    # bf16 activations + bf16 activation gradients through 9 layers: measured 0.7 - 4 % (relative L2)
+    assert all(v < 0.06 for k, v in report.items() if k.startswith("grad.")), report
+
+
+def long_video_batch(ragged, videos=2, vocab=2048, seed=11):
+    """configs[4] shapes: 256 frames, 64 subtitles x 4 frames, 20 tokens per subtitle, 15-token queries.
+    ragged: 256 / 201 frames, subtitles of 0-6 frames and 4-30 tokens, some frames matched to no subtitle."""
+    from hero_amd import synth
+    gen = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))   # noqa: E731
+    subs, n_frames, qlens = [], [], []
+    for v in range(videos):
+        if not ragged:
+            nf = 256
+            cur = [(list(range(s * 4, s * 4 + 4)), 20) for s in range(64)]
+            ql = 15
+        else:
+            nf = 256 if v == 0 else 201
+            cur, f0 = [], 0
+            for _ in range(64):
+                k = ri(0, 6)
+                fr = list(range(f0, min(f0 + k, nf - 3)))          # the last frames stay unmatched
+                f0 += len(fr)
+                cur.append((fr, ri(4, 30)))
+            ql = ri(5, 25)
+        subs.append(cur)
+        n_frames.append(nf)
+        qlens.append(ql)
+    batch = synth.video_batch(subs, n_frames, 4352, vocab, gen)
+    batch.update(synth.query_batch(videos, qlens, vocab, gen))
+    st = torch.tensor([ri(0, nf - 2) for nf in n_frames])
+    batch["targets"] = torch.stack([st, torch.minimum(st + 2, torch.tensor(n_frames) - 1)], dim=1)
+    batch["q_vidx"] = torch.arange(videos)
+    return batch
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_long_video_256_frame_temporal_transformer(ragged):
+    import hero_amd
+    from hero_amd import functional as HF
+    HF.set_grad_sink(None)
+    P, model = hero_base(seed=1)
+    batch = long_video_batch(ragged)
+    assert batch["c_v_feats"].shape[1] == 256
+    names = [n for n in GRAD_NAMES if "c_encoder" in n or "frame_transform" in n or "layer.5" in n]
+    ref_losses, ref_grads, ref_frames, R = oracle_losses_and_grads(batch, P, names)
+    b = to_dev(batch, "cuda")
+    # fp32 compute (exact-f32 MFMA GEMMs, fp32 attention at L = 256): forward parity with the oracle
+    hero_amd.set_compute_dtype(torch.float32)
+    HF.clear_weight_cache()
+    with torch.no_grad():
+        f32 = model.v_encoder(b, "repr")
+    assert rel_err(f32, ref_frames, batch["c_attn_masks"]) < FP32_TOL
+    # bf16 compute: matrix-core attention at L = 256 (forward + backward) against fp32 / the oracle
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.clear_weight_cache()
+    report = hip_report(model, b, batch, f32, ref_losses, ref_grads, R, names)
+    HF.clear_weight_cache()
+    assert report["repr.max"] < BF16_MAX_TOL and report["repr.l2"] < BF16_L2_TOL, report
+    assert all(v < 3e-2 for k, v in report.items() if k.startswith("loss.")), report
+    assert all(v < 0.06 for k, v in report.items() if k.startswith("grad.")), report
+
+
+def _train(use_graph, n_micro, sync_at):
+    """The bench's own configuration (HERO-base, bf16, D2 batch, dropout 0.1, TVR options) for n_micro micro-steps."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.step import TrainStep
+    from hero_amd.synth import make_batch
+    from hero_amd.utils.misc import set_dropout
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.set_grad_sink(None)
+    HF.clear_weight_cache()
+    _, model = hero_base(seed=2)
+    set_dropout(model, 0.1)
+    HF.manual_seed(5, "cuda")
+    b = make_batch("D2", vocab=2048, seed=9, device="cuda")
+    ts = TrainStep(model, use_graph=use_graph, static_usage=True)
+    losses = []
+    for i in range(n_micro):
+        losses.append(ts.micro_step(b).clone())
+        if i in sync_at:
+            torch.cuda.synchronize()                 # the queue runs dry: the pattern that exposed the memset-node race
+    torch.cuda.synchronize()
+    HF.set_grad_sink(None)
+    HF.clear_weight_cache()
+    return torch.stack(losses).float().cpu()
+
+
+def test_graph_replay_long_run_with_midrun_sync_converges_like_eager():
+    """Regression of 7a0be53 (a hipMemsetAsync NODE raced with the kernel accumulating into its buffer whenever
+    the queue had been idle): 5 of 13 replayed runs with a synchronise in them collapsed to the margin
+    solution (loss ~ 1.69, once NaN) after ~200 micro-steps, 0 of 29 eager runs did.  Both modes over-fit the one
+    synthetic batch within ~200 micro-steps when they are healthy."""
+    n, sync_at = 320, {40, 150, 151, 260}
+    l_e = _train(False, n + 4, sync_at)[4:]           # graph mode spends 4 eager warm-up micro-steps first
+    l_g = _train(True, n, {s - 4 for s in sync_at})
+    assert torch.isfinite(l_g).all() and torch.isfinite(l_e).all()
+    torch.testing.assert_close(l_g[:40], l_e[:40], rtol=5e-2, atol=5e-3)       # same trajectory early on
+    tail_e, tail_g = float(l_e[-20:].mean()), float(l_g[-20:].mean())
+    assert float(l_e[0]) > 1.0
+    assert tail_e < 0.3, tail_e                        # the eager run has over-fitted its one batch ...
+    assert tail_g < 0.3, tail_g                        # ... and the replayed run did too (not stuck at the margin terms)

@@ -239,7 +239,9 @@ def test_layernorm_fp32_in_bf16_out_and_tables(HF):
 @pytest.mark.parametrize("S,L,H", [(3, 9, 2), (5, 24, 12), (2, 60, 12), (2, 100, 3), (1, 130, 2), (4, 15, 12),
                                    (3, 32, 4), (2, 33, 2), (2, 64, 3), (41, 24, 12), (1, 1, 1), (2, 65, 2),
                                    (3, 128, 2), (2, 129, 3), (2, 200, 4), (3, 256, 12)])
-def test_attention_fwd_bwd(HF, dtype, S, L, H):
+def test_attention_fwd_bwd(HF, Lb, dtype, S, L, H):
+    """fp32: exact-f32 VALU kernels (forward L <= 256; backward up to hero_attention_max_len, 148 rows);
+    bf16: matrix-core kernels for every L <= 256."""
     D = H * 64
     qkv = rnd(S * L, 3 * D, dtype=dtype, seed=1)
     lens = [max(1, L - 3 * i) for i in range(S)]
@@ -258,6 +260,8 @@ def test_attention_fwd_bwd(HF, dtype, S, L, H):
     ref = (pr @ vv).permute(0, 2, 1, 3).reshape(S * L, D)
     torch.testing.assert_close(probs, pr, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-3)
     close(ctx, ref, dtype)
+    if L > Lb.lib().hero_attention_max_len(Lb.dt(qkv), 1):
+        return                                                    # forward-only length in this dtype
     ref.backward(dctx.float())
     dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, L, H, ctx=ctx)     # ctx: 64 < L <= 256 in bf16 runs on the matrix cores
     close(dqkv, q.grad, dtype, scale=2)
@@ -341,8 +345,9 @@ def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
     torch.testing.assert_close(probs16, probs32, rtol=2e-2, atol=2e-3)
     close(ctx16, ctx32, torch.bfloat16)
     d16 = HF.k_attn_bwd(qkv16, probs32, dctx16, S, L, H, drop=drop, ctx=ctx16)
-    d32 = HF.k_attn_bwd(qkv16.float(), probs32, dctx16.float(), S, L, H, drop=drop)
-    close(d16, d32, torch.bfloat16, scale=2)
+    if L <= 128:                                  # the fp32 backward is LDS-resident up to hero_attention_max_len(F32, 1)
+        d32 = HF.k_attn_bwd(qkv16.float(), probs32, dctx16.float(), S, L, H, drop=drop)
+        close(d16, d32, torch.bfloat16, scale=2)
     lhs = (dctx16.float() * ctx16.float()).sum()
     rhs = (d16[:, 2 * D:].float() * qkv16[:, 2 * D:].float()).sum()
     torch.testing.assert_close(lhs, rhs, rtol=2e-2, atol=0.5)

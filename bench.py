@@ -36,8 +36,12 @@ HERO_BASE = {  # config/hero_finetune.json
 }
 VFEAT = 4352
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
-SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (K-contiguous operands: forward x W^T and dgrad dY (W^T)^T)",
-              5: "gemm_kernel<bf16,K,O>", 7: "gemm_glds_tr_kernel (bf16 wgrad dY^T X)", 6: "gemm_kernel<bf16,O,K>"}
+SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (4-wave tiles, K-contiguous operands: the small-M forward / dgrad GEMMs)",
+              5: "gemm_kernel<bf16,K,O>", 7: "gemm_glds_tr_kernel (bf16 wgrad dY^T X, 128x128 tiles)", 6: "gemm_kernel<bf16,O,K>",
+              8: "gemm_ws_kernel<3,3,K,K> (wave-specialised persistent 192x192 tiles: forward x W^T and dgrad dY (W^T)^T "
+                 "of the M = 12000 row batch, fused epilogues)",
+              9: "gemm_ws_kernel<3,3,O,O> (wave-specialised 192x192 wgrad dY^T X)"}
+PROFILE_TRAFFIC = "r02_pmc_traffic.json"
 
 
 def algorithmic_flops_per_video(sh):
@@ -53,7 +57,24 @@ def algorithmic_flops_per_video(sh):
     return 3.0 * fwd / B
 
 
-def build_model(device, cfg_path):
+def algorithmic_flops_of_batch(batch):
+    """Same accounting on an arbitrary (ragged) batch: per sequence of L valid tokens one BertLayer forward is
+    24 L d^2 + 4 L^2 d; padded positions do not count."""
+    d = 768
+    layer = lambda lens: sum(24 * int(n) * d * d + 4 * int(n) * int(n) * d for n in lens)     # noqa: E731
+    lf = batch["f_attn_masks"].sum(1).tolist()
+    lq = batch["query_attn_masks"].sum(1).tolist()
+    lc = batch["c_attn_masks"].sum(1).tolist()
+    fwd = 6 * layer(lf) + 6 * layer(lq) + 3 * layer(lc)
+    n_fv = int((batch["f_attn_masks"][:, :batch["f_v_feats"].shape[1]] != 0).sum())
+    fwd += 2 * n_fv * VFEAT * d + 2 * int(sum(lc)) * VFEAT * d
+    fwd += sum(10 * int(n) * d * d + 4 * int(n) * int(n) * d for n in lq)
+    return 3.0 * fwd
+
+
+def build_model(device, cfg_path, pretraining=False):
+    if pretraining:
+        return build_pretraining_model(device, cfg_path)
     from hero_amd.model import HeroForVcmr
     from hero_amd.utils.misc import set_dropout
     torch.manual_seed(0)
@@ -61,6 +82,22 @@ def build_model(device, cfg_path):
         cfg_path, {}, vfeat_dim=VFEAT, max_frm_seq_len=100, lw_neg_ctx=8.0, lw_neg_q=8.0,
         lw_st_ed=0.01, ranking_loss_type="hinge", use_hard_negative=False, hard_pool_size=20,
         margin=0.1, use_all_neg=True, drop_svmr_prob=0.0)
+    model.to(device)
+    set_dropout(model, 0.1)
+    model.train()
+    return model
+
+
+def build_pretraining_model(device, cfg_path):
+    """config/hero_pretrain.json + pretrain.py:60-80: vocabulary 50265 padded to 50272 by pad_vocab()."""
+    from hero_amd.model import HeroForPretraining
+    from hero_amd.utils.misc import set_dropout
+    torch.manual_seed(0)
+    model = HeroForPretraining.from_pretrained(
+        cfg_path, {}, vfeat_dim=VFEAT, max_frm_seq_len=100, lw_neg_ctx=8.0, lw_neg_q=8.0,
+        lw_st_ed=0.01, ranking_loss_type="hinge", use_hard_negative=False, hard_pool_size=20,
+        margin=0.1, use_all_neg=True, drop_svmr_prob=0.0)
+    model.v_encoder.f_encoder.pad_vocab()
     model.to(device)
     set_dropout(model, 0.1)
     model.train()
@@ -92,6 +129,135 @@ def cpu_baseline(model, cfg, sample_videos=8, reps=3):
                       "median %.2f s" % (sample_videos, reps, med)}
 
 
+def _timed(trainer, batch, task, steps, warmup, world):
+    """prepare (untimed) + warm-up + `steps` micro-steps bracketed by barrier + synchronise; max over ranks."""
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+    trainer.prepare(batch, task)
+    for _ in range(warmup):
+        trainer.micro_step(batch, task)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = trainer.micro_step(batch, task)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=batch["c_v_feats"].device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, float(loss)
+
+
+def secondary_workload(args, device, world, rank):
+    """The other BASELINE.json configurations as bench lines of their own (same JSON contract, own `metric`)."""
+    from hero_amd.step import TrainStep
+    from hero_amd.synth import SHAPES, make_batch, make_pretrain_batches
+    cfg = json.loads(json.dumps(HERO_BASE))
+    graph = world == 1 and not args.no_graph
+    steps, warmup = args.steps + args.steps % 2, args.warmup + args.warmup % 2     # whole accumulation windows
+    base = {"unit": "videos/s", "n_gpus": world, "steps": steps, "warmup": warmup, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32",
+            "data": "synthetic"}
+    cfg_path = "/tmp/hero_bench_%s_%d.json" % (args.workload, rank)
+
+    if args.workload == "D2r":
+        with open(cfg_path, "w") as f:
+            json.dump(cfg, f)
+        model = build_model(device, cfg_path)
+        batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device, ragged=True)
+        trainer = TrainStep(model, use_graph=graph, static_usage=True)
+        dt, loss = _timed(trainer, batch, None, steps, warmup, world)
+        B = batch["c_v_feats"].shape[0]
+        vps = B * world * steps / dt
+        fl = algorithmic_flops_of_batch({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        out = dict(base, metric="videos/sec training step, HERO-base, ragged TVR batch (30-100 frames, 8-25 subtitles of "
+                                "0-8 frames and 4-40 tokens per video)",
+                   value=round(vps, 2), ms_per_step=round(dt / steps * 1e3, 3),
+                   config={"workload": "configs[1] ragged variant (SURVEY 8d): %d videos, %d subtitle rows, %d valid of %d "
+                                       "cross-modal positions (packed), fwd + VSM loss + bwd, clip/AdamW every 2nd micro-step"
+                                       % (B, batch["f_attn_masks"].shape[0], int(batch["f_attn_masks"].sum()),
+                                          batch["f_attn_masks"].numel()),
+                           "global_batch": B * world, "parallelism": "dp%d" % world, "dropout": 0.1, "grad_accum": 2,
+                           "launch": "hipGraph replay" if graph else "eager"},
+                   step_tflops=round(vps / B * fl / 1e12, 1),
+                   step_frac_of_bf16_peak=round(vps / B * fl / 1e12 / world / BF16_PEAK_TFLOPS, 4), final_loss=loss,
+                   peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+    elif args.workload == "D3":
+        cfg["f_config"]["vocab_size"] = 50265                      # config/hero_pretrain.json; pad_vocab() -> 50272
+        with open(cfg_path, "w") as f:
+            json.dump(cfg, f)
+        model = build_model(device, cfg_path, pretraining=True)
+        batches = make_pretrain_batches("D2", vfeat_dim=VFEAT, vocab=50265, seed=1 + rank, device=device)
+        opts = dict(learning_rate=3e-5, gradient_accumulation_steps=2)      # config/pretrain-tv-16gpu.json:33-34
+        trainer = TrainStep(model, opts=opts, task="vsm", use_graph=graph)
+        mix = {"mlm": 2, "mfm-nce": 2, "fom": 1, "vsm": 2}                  # config/pretrain-tv-16gpu.json:11-14
+        B = SHAPES["D2"]["videos"]
+        per_task, t_mix, losses = {}, 0.0, {}
+        for task, w in mix.items():                                         # fixed schedule, one task per window
+            dt, losses[task] = _timed(trainer, batches[task], task, steps, warmup, world)
+            per_task[task] = {"videos_per_s": round(B * world * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3)}
+            t_mix += w * dt / steps
+        vps = sum(mix.values()) * B * world / t_mix
+        out = dict(base, metric="videos/sec pre-training step, HERO-base, TV multi-task mix mlm:mfm-nce:fom:vsm = 2:2:1:2",
+                   value=round(vps, 2), ms_per_step=round(t_mix / sum(mix.values()) * 1e3, 3),
+                   config={"workload": "configs[3]: pretrain-tv-16gpu.json shapes per GPU (32 videos x 60 frames, 15 subs x "
+                                       "(4 frames + 20 tokens); 15 % masked tokens / frames, 15 % shuffled frames, 5 queries per "
+                                       "video; vocabulary 50265 padded to 50272); each task timed on its own, value = the "
+                                       "2:2:1:2 time-weighted mix",
+                           "global_batch": B * world, "parallelism": "dp%d" % world, "dropout": 0.1, "grad_accum": 2,
+                           "launch": "hipGraph replay" if graph else "eager"},
+                   per_task=per_task, final_loss=losses,
+                   peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+    else:   # D4
+        with open(cfg_path, "w") as f:
+            json.dump(cfg, f)
+        model = build_model(device, cfg_path)
+        trainer = TrainStep(model, use_graph=False, static_usage=True)
+        total = torch.cuda.get_device_properties(device).total_memory
+        B = args.videos
+        if B <= 0:      # probe the per-video footprint on a small batch, then size the batch to ~80 % of HBM
+            probe = make_batch("D4", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device, videos=48)
+            trainer.micro_step(probe)
+            trainer.micro_step(probe)
+            torch.cuda.synchronize()
+            del probe
+            torch.cuda.empty_cache()
+            fixed = torch.cuda.memory_allocated()                   # weights, optimiser state, gradient arena, copies
+            per_video = (torch.cuda.max_memory_allocated() - fixed) / 48.0
+            B = int((0.84 * total - fixed) / per_video)
+        while True:     # the caching allocator's peak is not exactly linear in the batch: back off on OOM
+            try:
+                torch.cuda.reset_peak_memory_stats()
+                batch = make_batch("D4", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device, videos=B)
+                dt, loss = _timed(trainer, batch, None, steps, warmup, world)
+                break
+            except torch.OutOfMemoryError:
+                batch = None
+                trainer.arena.zero()
+                torch.cuda.empty_cache()
+                B = int(B * 0.9)
+                if B < 8:
+                    raise
+        vps = B * world * steps / dt
+        fl = algorithmic_flops_of_batch({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        peak = torch.cuda.max_memory_allocated()
+        out = dict(base, metric="videos/sec training step, HERO-base, long-video stress (256 frames per video)",
+                   value=round(vps, 2), ms_per_step=round(dt / steps * 1e3, 3),
+                   config={"workload": "configs[4]: %d videos x 256 frames (64 subs x (4 frames + 20 tokens)), 256-frame "
+                                       "Temporal Transformer, fwd + VSM loss + bwd, clip/AdamW every 2nd micro-step" % B,
+                           "global_batch": B * world, "parallelism": "dp%d" % world, "dropout": 0.1, "grad_accum": 2,
+                           "launch": "eager"},
+                   step_tflops=round(vps / B * fl / 1e12, 1),
+                   step_frac_of_bf16_peak=round(vps / B * fl / 1e12 / world / BF16_PEAK_TFLOPS, 4), final_loss=loss,
+                   peak_mem_gb=round(peak / 2 ** 30, 2), hbm_frac=round(peak / total, 3))
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +267,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
+    ap.add_argument("--workload", default="D2", choices=["D2", "D2r", "D3", "D4"],
+                    help="D2 (default, the headline line): BASELINE configs[1]/[2]; secondary lines: D2r = ragged TVR "
+                         "batch (SURVEY 8d), D3 = configs[3] multi-task pre-training, D4 = configs[4] 256-frame videos "
+                         "with the batch sized to HBM")
+    ap.add_argument("--videos", type=int, default=0, help="D4: videos per step (0 = fill ~80 %% of HBM)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +297,11 @@ def main():
     from hero_amd.step import TrainStep
     from hero_amd.synth import SHAPES, make_batch
     hero_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    if args.workload != "D2":
+        secondary_workload(args, device, world, rank)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     cfg_path = "/tmp/hero_finetune_bench_%d.json" % rank
     with open(cfg_path, "w") as f:
         json.dump(HERO_BASE, f)
@@ -165,7 +341,7 @@ def main():
             trainer.micro_step(batch)
         torch.cuda.synchronize()
         best = None
-        for slot in range(8):
+        for slot in range(10):
             ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
             L.check(L.lib().hero_prof_read(slot, C.byref(ms), C.byref(fl), C.byref(n)))
             if n.value and (best is None or ms.value > best[1]):
@@ -174,18 +350,18 @@ def main():
         if best:
             slot, ms, fl, n = best
             ach = fl / (ms * 1e-3) / 1e12
-            peak = BF16_PEAK_TFLOPS if slot >= 4 else 157.3
+            peak = BF16_PEAK_TFLOPS if slot >= 4 else 157.3      # slots 0-3 are the fp32 parity-mode kernels
             traffic, tsrc = None, None
             try:                                   # HBM bytes per launch from the committed PMC passes
-                pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+                pj = os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)
                 pm = json.load(open(pj))
                 want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
-                        7: "gemm_glds_tr_kernel"}.get(slot)
+                        7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws_kernel<3, 3, true"}.get(slot)
                 hits = [v for k, v in pm.items() if want and want in k]
                 if hits:
                     tot = sum(h["launches"] for h in hits)
                     traffic = sum(h["hbm_bytes_per_launch_corrected"] * h["launches"] for h in hits) / tot
-                    tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+                    tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)" % PROFILE_TRAFFIC
             except Exception:
                 pass
             roof = {"bound": "mfma", "kernel": SLOT_NAMES.get(slot, "gemm slot %d" % slot),

@@ -536,12 +536,12 @@ template <int TM, int TN>
 static int launch_kk(const WsArgs& g, hipStream_t s) {
   const HeroGemmEpilogue& e = g.epi;
   const bool b = e.bias != nullptr, r = e.residual != nullptr, d = e.dropout.threshold16 != 0;
-  if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, 4, s);
-  if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, 4, s);
-  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, 4, s);
-  if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, 4, s);
-  if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, 4, s);
-  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, 4, s);
+  if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, 8, s);
+  if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, 8, s);
+  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, 8, s);
+  if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, 8, s);
+  if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, 8, s);
+  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, 8, s);
   return -1;
 }
 
@@ -605,7 +605,7 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
     const int rc = check_launch("hero_gemm(ws scale)");
     if (rc) return rc;
   }
-  return launch<3, 3, true, 0>(g, 7, s);
+  return launch<3, 3, true, 0>(g, 9, s);
 }
 
 }  // namespace hero

@@ -516,8 +516,21 @@ def memo(tag, tensors, fn, extra=()):
     if len(_MEMO) > 512:
         _MEMO.clear()
     out = fn()
-    _MEMO[key] = (out, tensors)
+    _MEMO[key] = (out, tensors, fn)
     return out
+
+
+def refresh_memo():
+    """Recompute every memoised derived tensor IN PLACE from the current contents of its sources.  For callers
+    that rewrite batch buffers in place (hero_amd.collate.DeviceCollate, or new data copied into a captured
+    batch): captured graphs and cached maps hold the derived tensors by address."""
+    for out, _, fn in list(_MEMO.values()):
+        new = fn()
+        if isinstance(out, torch.Tensor):
+            if new.shape != out.shape:
+                raise RuntimeError("refresh_memo: a derived tensor changed shape %s -> %s; the batch structure is "
+                                   "different, not just its contents" % (tuple(out.shape), tuple(new.shape)))
+            out.copy_(new)
 
 
 def as_mask_add(mask, S, Lq):
@@ -595,6 +608,11 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None):
+    if x.dtype == torch.bfloat16 and weight.shape[0] % 8 != 0:
+        # a bf16 GEMM operand row must be a multiple of 16 bytes; narrow heads whose width is not (the 100
+        # frame-order classes of fom_output, model/model.py:118) run in fp32 - they are tiny
+        x = cast(x, torch.float32)
+        residual = cast(residual, torch.float32) if residual is not None else None
     return LinearFn.apply(x, weight, bias, act, residual)
 
 

@@ -196,8 +196,9 @@ class CrossModalTrm(RobertaPreTrainedModel):
         emb = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_ids,
                                                gather_index)
         seq = self.encoder(emb, attention_mask)[0]
-        rows = torch.nonzero(txt_mask_tgt.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32)
-        masked = HF.GatherRowsFn.apply(seq.reshape(-1, seq.shape[-1]), None, rows.contiguous())
+        rows = HF.memo("mask_rows", (txt_mask_tgt,),     # once per batch object: nonzero synchronises (no graph capture)
+                       lambda: torch.nonzero(txt_mask_tgt.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32).contiguous())
+        masked = HF.GatherRowsFn.apply(seq.reshape(-1, seq.shape[-1]), None, rows)
         if compute_loss:      # fused log-softmax + NLL over the vocabulary GEMM output, padding columns excluded
             logits = self.lm_head(masked, raw=True)
             return HF.cross_entropy(logits, txt_labels, ncols=logits.shape[1] - self.vocab_pad)

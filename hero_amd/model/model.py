@@ -145,11 +145,13 @@ class HierarchicalVlModel(VideoPreTrainedModel):
             self._frame_maps[key] = hit
         return hit[1]
 
-    def collect_frame_outputs(self, out_shape, frame_sequence_output, num_subs, sub_idx2frame_idx):
+    def collect_frame_outputs(self, out_shape, frame_sequence_output, num_subs, sub_idx2frame_idx, frame_map=None):
+        """frame_map: (offsets, entries, inverse) already on the device (hero_amd.collate.DeviceCollate) instead of
+        the collate's python lists."""
         B, NF, D = out_shape
         Lf = frame_sequence_output.shape[1]
-        offs, ent, inv = self._frame_map(num_subs, sub_idx2frame_idx, B, NF, Lf,
-                                         frame_sequence_output.device)
+        offs, ent, inv = frame_map if frame_map is not None else \
+            self._frame_map(num_subs, sub_idx2frame_idx, B, NF, Lf, frame_sequence_output.device)
         out = HF.CsrGatherSumFn.apply(frame_sequence_output, offs, ent, inv, B * NF)
         return out.view(B, NF, D)
 
@@ -162,7 +164,7 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         c_v_feats, c_attn_masks = batch["c_v_feats"], batch["c_attn_masks"]
         shape = list(c_v_feats.shape[:2]) + [f_seq.shape[-1]]
         matched = self.collect_frame_outputs(shape, f_seq, batch["num_subs"],
-                                             batch["sub_idx2frame_idx"])
+                                             batch["sub_idx2frame_idx"], frame_map=batch["frame_map"])
         # ReLU(Linear(drop(LN(c_v_feats)))) + matched, residual fused into the GEMM epilogue
         fused = self.frame_transform(c_v_feats, residual=matched)
         if not encode_clip:
@@ -179,10 +181,14 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         return clip_outputs, q
 
     # -- pre-training heads (config 4) ---------------------------------------------------------------
-    def _compute_masked_hidden(self, hidden, mask):
-        rows = torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32)
-        return HF.GatherRowsFn.apply(hidden.reshape(-1, hidden.shape[-1]).contiguous(), None,
-                                     rows.contiguous())
+    def _compute_masked_hidden(self, hidden, mask, invert=False):
+        """Rows of `hidden` where mask (or ~mask) is set (model/model.py:_compute_masked_hidden).  The row list is
+        derived once per batch object (torch.nonzero synchronises and cannot be captured in a hipGraph)."""
+        def build():
+            m = ~mask if invert else mask
+            return torch.nonzero(m.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32).contiguous()
+        rows = HF.memo("mask_rows", (mask,), build, (invert,))
+        return HF.GatherRowsFn.apply(hidden.reshape(-1, hidden.shape[-1]).contiguous(), None, rows)
 
     def forward_mfm(self, batch, compute_loss=True, loss="regression"):
         assert loss in ("regression", "nce")
@@ -192,7 +198,7 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         batch["c_v_feats"] = c_v_feats + self.mask_embedding(c_v_mask.long())
         clip_outputs = self.forward_repr(batch)
         pred = self.feat_regress(self._compute_masked_hidden(clip_outputs, c_v_mask))
-        neg = self.feat_regress(self._compute_masked_hidden(clip_outputs, ~c_v_mask)) \
+        neg = self.feat_regress(self._compute_masked_hidden(clip_outputs, c_v_mask, invert=True)) \
             if loss == "nce" else None
         if not compute_loss:
             return pred if loss == "regression" else (pred, neg)

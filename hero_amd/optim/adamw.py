@@ -26,7 +26,7 @@ class AdamW(Optimizer):
         if len(self.param_groups) > 8:
             raise ValueError("hero_amd AdamW supports up to 8 parameter groups")
         self._global_step = 0
-        self._table = None        # (signature, device tensors, n_chunks)
+        self._tables = {}         # signature -> (device tensors, n_chunks); kept alive: captured graphs hold their pointers
 
     # ---- gradient norm ---------------------------------------------------------------------------
     def grad_sumsq(self, flat=None):
@@ -90,9 +90,11 @@ class AdamW(Optimizer):
             return loss
         sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self._global_step - self.state[p]["step"])
                     for _, p in active)
-        if self._table is None or self._table[0] != sig:
-            self._table = (sig,) + self._build_table(active)
-        _, raw, t_ct, t_ci, n_chunks = self._table
+        if sig not in self._tables:
+            if len(self._tables) >= 16 and not torch.cuda.is_current_stream_capturing():
+                self._tables.clear()              # eager multi-task runs change the signature often
+            self._tables[sig] = self._build_table(active)
+        raw, t_ct, t_ci, n_chunks = self._tables[sig]
         a = L.AdamWMulti()
         a.descs, a.chunk_tensor, a.chunk_index, a.n_chunks = raw.data_ptr(), t_ct.data_ptr(), t_ci.data_ptr(), n_chunks
         for gi, group in enumerate(self.param_groups):

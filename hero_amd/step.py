@@ -38,32 +38,43 @@ def qkv_groups(model):
 
 
 class TrainStep:
-    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=False):
+    def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=False,
+                 grad_compress="bf16"):
         """static_usage: the set of parameters that receive gradients only grows over the run (single-task
         fine-tuning with drop_svmr_prob = 0, as bench.py runs it) - lets the gradient buckets that also
         hold never-used parameters overlap with backward too.  Off by default: the reference configs
-        drop the st/ed head on 80 % of the steps (config/train-tvr-8gpu.json:30)."""
+        drop the st/ed head on 80 % of the steps (config/train-tvr-8gpu.json:30).
+        grad_compress: 'bf16' (default) sends the gradient buckets as bf16 - the reference's payload is fp16
+        (train-tvr-8gpu.json:67 "fp16": true) - None keeps fp32 on the wire."""
         self.model = model
         self.opts = SimpleNamespace(**{**TVR_OPTS, **(opts or {})})
         self.task = task
         self.optimizer = build_optimizer(model, self.opts)
         self.arena = D.GradArena(list(model.parameters()), bucket_bytes=bucket_bytes,
-                                 groups=qkv_groups(model), static_usage=static_usage)
+                                 groups=qkv_groups(model), static_usage=static_usage,
+                                 compress=grad_compress if D.world_size() > 1 else None)
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152
         self.use_graph = use_graph and D.world_size() == 1
-        self._graphs = None
+        self._graphs = {}             # task -> (plain graph, its loss, boundary graph, its loss, static batch)
+        self._window = []             # tasks of the micro-steps accumulated since the last optimiser step
+        # compute copies of the weights are cached per optimiser step: anything else that rewrites parameters
+        # (checkpoint restore, EMA swap) must invalidate them
+        model.register_load_state_dict_post_hook(lambda *_: HF.notify_weights_updated())
         dev = next(model.parameters()).device
         self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side optimiser step
         self._lr_t = torch.zeros(8, dtype=torch.float32, device=dev)
 
     # ---- pieces ------------------------------------------------------------------------------------
-    def _fwd_bwd(self, batch):
+    def _fwd_bwd(self, batch, task=None):
         HF.advance_seed()
         with HF.weights_frozen():                   # inside the step only the optimiser changes weights
-            l_st_ed, l_ctx, l_q = self.model(batch, task=self.task, compute_loss=True)
-            loss = (l_st_ed + l_ctx + l_q).mean()
+            out = self.model(batch, task=task or self.task, compute_loss=True)
+            # 'tvr' / 'vsm': (loss_st_ed, loss_neg_ctx, loss_neg_q) summed (train_vcmr.py:216-226, pretrain.py:283-290);
+            # 'mlm' / 'mfm-nce' / 'fom': one loss tensor
+            loss = (out[0] + out[1] + out[2]) if isinstance(out, (tuple, list)) else out
+            loss = loss.mean()
             loss.backward()
         return loss.detach()
 
@@ -88,15 +99,17 @@ class TrainStep:
         return lr
 
     # ---- eager -------------------------------------------------------------------------------------
-    def micro_step(self, batch):
+    def micro_step(self, batch, task=None):
         """One forward+backward; optimiser step on accumulation boundaries. Returns the loss
-        tensor (device-resident, not synchronised)."""
+        tensor (device-resident, not synchronised).  task: this micro-step's task (multi-task
+        pre-training, pretrain.py:274-350); default: the task given at construction."""
+        task = task or self.task
         if self.use_graph:
-            return self._graph_step(batch)
+            return self._graph_step(batch, task)
         accum = self.opts.gradient_accumulation_steps
         boundary = (self.micro + 1) % accum == 0
         self.arena.set_sync(boundary)
-        loss = self._fwd_bwd(batch)
+        loss = self._fwd_bwd(batch, task)
         self.micro += 1
         if boundary:
             self._set_lr()
@@ -104,17 +117,21 @@ class TrainStep:
         return loss
 
     # ---- hipGraph ------------------------------------------------------------------------------------
-    def _capture(self, batch):
+    def _capture(self, batch, task):
         """Warm up eagerly (all lazy state: kernel attributes, index maps, workspaces, optimiser
         tables), then capture two graphs on the same static batch: plain micro-step and boundary
         micro-step (with clip + AdamW + weight-copy refresh + gradient zeroing)."""
+        if getattr(self.model, "drop_svmr_prob", 0) > 0 and getattr(self.model, "lw_st_ed", 0) != 0:
+            raise RuntimeError("graph mode cannot capture a step whose loss terms are drawn per step on the host "
+                               "(drop_svmr_prob > 0, model/pretrain.py:74-75): the branch taken at capture would be replayed "
+                               "forever; run eagerly")
         accum = self.opts.gradient_accumulation_steps
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for i in range(2 * accum):
                 self.arena.set_sync((i + 1) % accum == 0)
-                self._fwd_bwd(batch)
+                self._fwd_bwd(batch, task)
                 if (i + 1) % accum == 0:
                     lr = self._set_lr()
                     self._lr_t.fill_(lr)
@@ -124,31 +141,44 @@ class TrainStep:
         self.micro += 2 * accum
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
-            loss_a = self._fwd_bwd(batch)
+            loss_a = self._fwd_bwd(batch, task)
         with torch.cuda.graph(gb, pool=ga.pool()):
-            loss_b = self._fwd_bwd(batch)
+            loss_b = self._fwd_bwd(batch, task)
             self._optimise(device_state=True)
-        self._graphs = (ga, loss_a, gb, loss_b, batch)
+        self._graphs[task] = (ga, loss_a, gb, loss_b, batch)
 
-    def prepare(self, batch):
+    def prepare(self, batch, task=None):
         """One-time setup outside any timed region: in graph mode the eager warm-up micro-steps and the
-        capture of the two graphs on `batch`'s buffers (a no-op otherwise / when already done)."""
+        capture of the two graphs of `task` on `batch`'s buffers (a no-op otherwise / when already done)."""
+        task = task or self.task
         if self.use_graph:
-            if self._graphs is None:
-                self._capture(batch)
-        elif not getattr(self, "_prepared", False):
+            if task not in self._graphs:
+                self._capture(batch, task)
+        elif task not in getattr(self, "_prepared", set()):
             for _ in range(self.opts.gradient_accumulation_steps):   # one full cycle: every lazy state exists
-                self.micro_step(batch)
-            self._prepared = True
+                self.micro_step(batch, task)
+            self._prepared = getattr(self, "_prepared", set()) | {task}
 
-    def _graph_step(self, batch):
-        if self._graphs is None:
-            self._capture(batch)
-        ga, loss_a, gb, loss_b, static_batch = self._graphs
+    def _graph_step(self, batch, task):
+        """Replay of the graphs captured for `task`.  The captured region holds everything that was decided on the
+        host while capturing: the batch's index / mask / pack-plan tensors, and the set of parameters the optimiser
+        skips.  Hence (a) only the captured batch OBJECT is accepted - new data of identical structure (same masks,
+        lengths, frame maps) may be copied into its tensors, anything else needs a new capture; (b) all micro-steps
+        of one accumulation window must be of the same task."""
+        if task not in self._graphs:
+            self._capture(batch, task)
+        ga, loss_a, gb, loss_b, static_batch = self._graphs[task]
         if batch is not static_batch:
-            raise RuntimeError("graph mode replays the captured batch buffers; copy new data into them")
+            raise RuntimeError("graph mode replays the captured batch buffers (and the index / mask tensors derived "
+                               "from them at capture): copy new data of the SAME structure into them, or run eagerly")
         accum = self.opts.gradient_accumulation_steps
         boundary = (self.micro + 1) % accum == 0
+        self._window.append(task)
+        if len(set(self._window)) > 1:
+            raise RuntimeError("graph mode: one accumulation window mixes tasks %s; the captured optimiser step only "
+                               "updates the parameters of its own task" % sorted(set(self._window)))
+        if boundary:
+            self._window = []
         self.micro += 1
         if boundary:
             self._lr_t.fill_(self._set_lr())        # stream-ordered scalar fill (no pinned-buffer race)
@@ -156,3 +186,29 @@ class TrainStep:
             return loss_b
         ga.replay()
         return loss_a
+
+    # ---- checkpointing ---------------------------------------------------------------------------------
+    def _sync_optimizer_steps(self):
+        """hipGraph replays advance the optimiser step on the device only; bring the host-side counters
+        (bias-correction steps in optimizer.state) up to date before they are saved."""
+        delta = self.global_step - self.optimizer._global_step
+        if delta > 0:
+            self.optimizer._global_step += delta
+            for st in self.optimizer.state.values():
+                if "step" in st:
+                    st["step"] += delta
+
+    def state_dict(self):
+        self._sync_optimizer_steps()
+        return {"global_step": self.global_step, "micro": self.micro, "optimizer": self.optimizer.state_dict(),
+                "optimizer_global_step": self.optimizer._global_step}
+
+    def load_state_dict(self, sd):
+        if self._graphs:
+            raise RuntimeError("restore the training state before the first graph-mode step (captured graphs hold "
+                               "the optimiser's device state)")
+        self.optimizer.load_state_dict(sd["optimizer"])
+        self.optimizer._global_step = sd["optimizer_global_step"]
+        self.global_step, self.micro = sd["global_step"], sd["micro"]
+        self._step_t.fill_(self.global_step)
+        HF.notify_weights_updated()

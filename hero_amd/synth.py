@@ -122,3 +122,91 @@ def make_batch(name="D2", vfeat_dim=4352, vocab=50272, seed=1, device="cpu", rag
     batch["targets"] = torch.stack([st, ed], dim=1)
     batch["q_vidx"] = torch.arange(B)
     return to_device(batch, device)
+
+
+# ---- pre-training tasks (BASELINE configs[3], config/pretrain-tv-16gpu.json) ---------------------------
+MASK_ID = 4      # any in-vocabulary id stands in for <mask>; the token it replaces is the label
+
+
+def make_pretrain_batches(name="D2", vfeat_dim=4352, vocab=50272, seed=1, device="cpu", mask_prob=0.15,
+                          queries_per_video=5):
+    """One synthetic batch per pre-training task on the same videos, with the batch keys of the reference's
+    collates: 'mlm' (data/mlm.py:134-176), 'mfm-nce' (data/mfm.py:77-97), 'fom' (data/fom.py:50-93), 'vsm'
+    (data/vsm.py:105-145: `queries_per_video` queries for every video)."""
+    sh = dict(SHAPES[name])
+    gen = torch.Generator().manual_seed(seed)
+    B = sh["videos"]
+    subs = [[(list(range(s * sh["fps"], (s + 1) * sh["fps"])), sh["toks"]) for s in range(sh["subs"])]
+            for _ in range(B)]
+    n_frames = [sh["frames"]] * B
+    vb = video_batch(subs, n_frames, vfeat_dim, vocab, gen)
+    T, max_vl = vb["f_v_feats"].shape[:2]
+    Lf = vb["f_attn_masks"].shape[1]
+    out = {}
+
+    # MLM: 15 % of the sub-tokens (never the leading SEP) are replaced by <mask>; targets live in the
+    # interleaved (frames first, then tokens) layout of f_attn_masks
+    ids = vb["f_sub_input_ids"].clone()
+    tok = torch.zeros_like(ids, dtype=torch.bool)
+    r = 0
+    for vs in subs:
+        for fr, nt in vs:
+            tok[r, 1:nt] = True
+            r += 1
+    pick = tok & (torch.rand(ids.shape, generator=gen) < mask_prob)
+    if not pick.any():
+        pick[0, 1] = True
+    tgt = torch.zeros(T, Lf, dtype=torch.bool)
+    r = 0
+    for vs in subs:
+        for fr, nt in vs:
+            nf = max(len(fr), 1)
+            tgt[r, nf:nf + ids.shape[1]][: Lf - nf] = pick[r][: Lf - nf]
+            r += 1
+    labels = ids[pick]                                      # row-major order == nonzero order of tgt
+    ids = ids.masked_fill(pick, MASK_ID)
+    out["mlm"] = {"input_ids": ids, "position_ids": vb["f_sub_pos_ids"], "v_feat": vb["f_v_feats"],
+                  "f_pos_ids": vb["f_v_pos_ids"], "attn_masks": vb["f_attn_masks"],
+                  "gather_index": vb["f_gather_index"], "txt_mask_tgt": tgt, "txt_labels": labels}
+
+    # MFM: 15 % of the frames, masked in the clip stream and in the subtitle that carries them
+    cm = (torch.rand(B, max(n_frames), generator=gen) < mask_prob) & vb["c_attn_masks"].bool()
+    cm[0, 0] = True
+    fm = torch.zeros(T, max_vl, dtype=torch.bool)
+    r = 0
+    for b, vs in enumerate(subs):
+        for fr, nt in vs:
+            for k, f in enumerate(fr):
+                fm[r, k] = cm[b, f]
+            r += 1
+    mfm = dict(vb)
+    mfm["feat_targets"] = vb["c_v_feats"][cm].clone()
+    mfm["c_v_feats"] = vb["c_v_feats"].masked_fill(cm.unsqueeze(-1), 0)
+    mfm["f_v_feats"] = vb["f_v_feats"].masked_fill(fm.unsqueeze(-1), 0)
+    mfm["c_v_masks"], mfm["f_v_masks"] = cm, fm
+    out["mfm-nce"] = mfm
+
+    # FOM: 15 % of the frames of every video are permuted among themselves
+    Lc = max(n_frames)
+    orders = torch.arange(Lc).unsqueeze(0).repeat(B, 1)
+    targets = torch.full((B, Lc), -1, dtype=torch.long)
+    for b, nf in enumerate(n_frames):
+        k = max(2, int(round(nf * mask_prob)))
+        pos = torch.randperm(nf, generator=gen)[:k]
+        perm = pos[torch.randperm(k, generator=gen)]
+        orders[b, pos] = perm
+        targets[b, perm] = pos
+    fom = dict(vb)
+    fom["shuffled_orders"], fom["targets"] = orders, targets
+    out["fom"] = fom
+
+    # VSM: several queries per video (query m belongs to video m // queries_per_video)
+    nq = B * queries_per_video
+    vsm = dict(vb)
+    vsm.update(query_batch(nq, [sh["qtoks"]] * nq, vocab, gen))
+    st = torch.randint(0, sh["frames"] - 2, (nq,), generator=gen)
+    vsm["targets"] = torch.stack([st, torch.clamp(st + 1 + torch.randint(0, 4, (nq,), generator=gen),
+                                                 max=sh["frames"] - 1)], dim=1)
+    vsm["q_vidx"] = torch.arange(nq) // queries_per_video
+    out["vsm"] = vsm
+    return {k: to_device(v, device) for k, v in out.items()}

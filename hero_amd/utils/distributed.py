@@ -92,7 +92,7 @@ class GradArena(HF.GradSink):
     """
 
     def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True, groups=(),
-                 static_usage=False):
+                 static_usage=False, compress=None):
         """groups: tuples of parameters whose gradients must be CONTIGUOUS in the arena, in the given
         order (e.g. an attention block's query/key/value weights: the backward then writes
         d[Wq;Wk;Wv] with one GEMM instead of three, see hero_amd.functional._qkv_bwd)."""
@@ -133,6 +133,13 @@ class GradArena(HF.GradSink):
             p.grad = self.flat[s:e].view_as(p)
         self.sync = True
         self.overlap = overlap
+        # compress="bf16": a bucket travels as bf16 (the reference all-reduces fp16 gradients: 242 MB instead of
+        # 484 MB per optimiser step, utils/distributed.py:27-38 under amp O2) - cast into a per-bucket wire buffer
+        # when the bucket is issued, summed by RCCL in bf16, widened back into the fp32 arena in finish()
+        self.compress = compress
+        if compress not in (None, "bf16"):
+            raise ValueError("GradArena: compress must be None or 'bf16'")
+        self._wire = {}
         # static_usage: the caller guarantees that every optimiser step touches the same parameters
         # (one task, fixed graph).  Buckets then wait only for the parameters that received a gradient
         # in the previous step, so a bucket that also holds never-used parameters (pooler, lm_head,
@@ -219,7 +226,14 @@ class GradArena(HF.GradSink):
             return
         self._launched[b] = True
         s, e, _ = self.buckets[b]
-        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        if self.compress == "bf16":
+            w = self._wire.get(b)
+            if w is None:
+                w = self._wire[b] = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+            w.copy_(self.flat[s:e])
+            self._handles.append((dist.all_reduce(w, op=dist.ReduceOp.SUM, async_op=True), b))
+        else:
+            self._handles.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True), None))
 
     def set_sync(self, flag):
         """Call at the start of every micro-step; False on gradient-accumulation micro-steps that do
@@ -233,8 +247,11 @@ class GradArena(HF.GradSink):
         if world_size() > 1 and self.sync:
             for b in range(len(self.buckets)):
                 self._launch(b)
-            for h in self._handles:
+            for h, b in self._handles:
                 h.wait()
+                if b is not None:                       # widen the summed wire buffer back into the arena
+                    s, e, _ = self.buckets[b]
+                    self.flat[s:e].copy_(self._wire[b])
         self._handles = []
         if self.static_usage and self.touched:
             # union over all steps so far: a parameter that is used only on some steps (drop_svmr_prob,

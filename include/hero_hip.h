@@ -86,7 +86,8 @@ int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
 
 /* Per-launch timing of hero_gemm with HIP events recorded on the launch stream (bench.py's
  * roofline leg; off by default, never enable inside graph capture).
- * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout. hero_prof_read synchronises. */
+ * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout for the 4-wave kernels, 8 / 9 for the
+ * wave-specialised K,K / O,O kernels (gemm_ws.hip). hero_prof_read synchronises. */
 int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
                                       * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
                                       * bits 8+: M-tiles per L2 locality group; -1 heuristic */
@@ -409,6 +410,24 @@ typedef struct HeroCrossEntropy {
 } HeroCrossEntropy;
 int hero_cross_entropy_fwd(const HeroCrossEntropy* a, hero_stream_t stream);
 int hero_cross_entropy_bwd(const HeroCrossEntropy* a, hero_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Collate on the device: the index tensors of a batch from per-subtitle / per-video length      */
+/* arrays (data/data.py:406-512 video_collate + get_gather_index; the python walk of             */
+/* sub_idx2frame_idx in model/model.py:156-187).  All arrays int32 on the device.                */
+/* ------------------------------------------------------------------------------------------ */
+/* gather_index / attn_mask [T, max_vl + max_sl] int64 (data/data.py:504-512, 380-382) */
+int hero_collate_subs(const int32_t* sub_nfrm, const int32_t* sub_ntok, int64_t* gather_index, int64_t* attn_mask, int T,
+                      int max_vl, int max_sl, hero_stream_t stream);
+/* attn_mask [B, NF] int64 = f < vid_nfrm[b] */
+int hero_collate_clip_mask(const int32_t* vid_nfrm, int64_t* attn_mask, int B, int NF, hero_stream_t stream);
+/* Frame map of collect_frame_outputs, two passes around an exclusive scan done by the caller:       */
+/* fill = 0: counts[b * NF + f] = number of (subtitle, slot) pairs matched to frame f of video b;     */
+/* fill = 1: entries[offsets[bf] ...] = flat source rows (subtitle row * Lf + slot) in subtitle /     */
+/* slot order, inverse[source row] = bf (inverse must be pre-filled with -1).                         */
+int hero_collate_frame_map(const int32_t* vid_sub_off, const int32_t* sub_frm_off, const int32_t* sub_frm, const int32_t* offsets,
+                           int32_t* counts, int32_t* entries, int32_t* inverse, int B, int NF, int Lf, int fill,
+                           hero_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -34,8 +34,11 @@ def main():
                 p.add_(0.01)
     set_dropout(model, 0.0)
     model.train()
+    wire = sys.argv[2] if len(sys.argv) > 2 else "none"          # gradient wire format: fp32 (exact check) or bf16
+    tol = 1e-5 if wire == "none" else 2.0 ** -6
     trainer = TrainStep(model, opts={"gradient_accumulation_steps": 2, "learning_rate": 1e-3}, use_graph=False,
-                        bucket_bytes=64 << 10)        # small buckets -> many overlapped all-reduces
+                        bucket_bytes=64 << 10,        # small buckets -> many overlapped all-reduces
+                        grad_compress=None if wire == "none" else wire)
     named = dict(model.named_parameters())
     # (1) parameters were broadcast from rank 0
     chk = torch.stack([p.detach().double().sum() for p in named.values()])
@@ -66,7 +69,7 @@ def main():
         trainer.arena.finish()
         got = trainer.arena.flat.clone()
         err = (got - want_sum).abs().max().item() / max(want_sum.abs().max().item(), 1e-12)
-        if err >= 1e-5:
+        if err >= tol:
             bad = []
             for n_, p_ in named.items():
                 s_, e_ = trainer.arena.slices[p_]
@@ -74,7 +77,7 @@ def main():
                 if d_ > 1e-6 * max(want_sum.abs().max().item(), 1e-12):
                     bad.append((round(d_ / max(want_sum[s_:e_].abs().max().item(), 1e-12), 4), n_, trainer.arena.bucket_of[p_]))
             print("RANK", rank, "mismatching parameters:", sorted(bad, reverse=True)[:12], flush=True)
-        assert err < 1e-5, "bucketed all-reduce != sum of local gradients (rel %g)" % err
+        assert err < tol, "bucketed all-reduce != sum of local gradients (rel %g, wire %s)" % (err, wire)
         errs.append(err)
     err = max(errs)
     nb = len(trainer.arena.buckets)

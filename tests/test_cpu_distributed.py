@@ -176,6 +176,38 @@ def test_grad_arena_intermittent_parameter():
     assert all(spawn(_arena_intermittent))
 
 
+def _arena_bf16_wire(rank, world):
+    """compress='bf16': the buckets are summed in bf16 on the wire (the reference's fp16 payload) and widened
+    back into the fp32 arena; the result is the bf16-rounded sum of the bf16-rounded local gradients."""
+    from hero_amd import functional as HF
+    from hero_amd.utils import distributed as D
+    torch.manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(40, 6))
+    w2 = torch.nn.Parameter(torch.randn(6, 6))
+    arena = D.GradArena([w1, w2], bucket_bytes=64, overlap=True, compress="bf16")
+
+    def local(r):
+        x = torch.randn(4, 40, generator=torch.Generator().manual_seed(30 + r))
+        a, b = w1.detach().clone().requires_grad_(), w2.detach().clone().requires_grad_()
+        ((x @ a) @ b).sum().backward()
+        return a.grad, b.grad
+
+    arena.set_sync(True)
+    x = torch.randn(4, 40, generator=torch.Generator().manual_seed(30 + rank))
+    ((x @ w1) @ w2).sum().backward()
+    arena.finish()
+    ok = True
+    for p, i in ((w1, 0), (w2, 1)):
+        want = sum(local(r)[i].to(torch.bfloat16).float() for r in range(world))
+        ok = ok and torch.allclose(p.grad, want, rtol=2 ** -7, atol=1e-3) and p.grad.dtype == torch.float32
+    HF.set_grad_sink(None)
+    return bool(ok)
+
+
+def test_grad_arena_bf16_wire_format():
+    assert all(spawn(_arena_bf16_wire))
+
+
 def _negatives(rank, world):
     from hero_amd.utils import distributed as D
     torch.manual_seed(rank)

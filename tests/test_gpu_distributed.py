@@ -11,13 +11,34 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_data_parallel_real_kernels(tmp_path):
+@pytest.mark.parametrize("wire", ["none", "bf16"])
+def test_two_rank_data_parallel_real_kernels(tmp_path, wire):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), wire]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in range(2)]
     assert res[0]["buckets"] > 3                      # several overlapped buckets were exercised
     assert res[0]["losses"] != res[1]["losses"]       # different data per rank, same weights
+
+
+def test_bench_two_ranks_end_to_end_on_one_device():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with
+    both ranks on the box's single GPU and gloo as the transport (HERO_BENCH_ONE_DEVICE / HERO_BENCH_BACKEND):
+    process-group setup, parameter broadcast, bucketed bf16 gradient all-reduce overlapped with backward,
+    cross-rank negatives, max-over-ranks timing and the one JSON line on rank 0."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_BENCH_ONE_DEVICE="1",
+               HERO_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 64 and out["config"]["launch"] == "eager"
+    assert out["final_loss"] == out["final_loss"] and out["roofline"]["frac"] > 0      # finite loss, GEMM events recorded

@@ -353,6 +353,44 @@ def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
     torch.testing.assert_close(lhs, rhs, rtol=2e-2, atol=0.5)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("rows,cols,ld", [(37, 50265, 50272), (5, 100, 100), (64, 1931, 1936), (3, 7, 7)])
+def test_cross_entropy_matches_torch(HF, dtype, rows, cols, ld):
+    """hero_cross_entropy_fwd/bwd (MLM vocabulary rows with padding columns, NCE with a temperature, FOM with
+    ignore_index) against F.cross_entropy on the same logits."""
+    x = rnd(rows, ld, dtype=dtype, seed=1, scale=3.0)
+    g = torch.Generator().manual_seed(2)
+    y = torch.randint(0, cols, (rows,), generator=g).cuda()
+    y[0] = -1
+    w = rnd(rows, seed=3).abs() + 0.5
+    for temp in (1.0, 0.7):
+        xr = x.float()[:, :cols].clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(xr / temp, y, ignore_index=-1, reduction="none")
+        (ref * w).sum().backward()
+        xh = x.clone().requires_grad_(True)
+        got = HF.cross_entropy(xh, y, ncols=cols, ignore_index=-1, inv_temp=1.0 / temp)
+        (got * w).sum().backward()
+        torch.testing.assert_close(got, ref.detach(), rtol=1e-4, atol=1e-4)
+        tol = dict(rtol=1e-4, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+        torch.testing.assert_close(xh.grad.float()[:, :cols], xr.grad, **tol)
+        assert float(xh.grad.float()[:, cols:].abs().sum()) == 0.0 and float(xh.grad.float()[0].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_matmul_nt_activations(HF, dtype):
+    a = rnd(130, 4352, dtype=dtype, seed=1, scale=0.1).requires_grad_(True)
+    b = rnd(1936, 4352, dtype=dtype, seed=2, scale=0.1).requires_grad_(True)
+    y = HF.matmul_nt(a, b)
+    af, bf = a.detach().float().requires_grad_(True), b.detach().float().requires_grad_(True)
+    ref = af @ bf.t()
+    close(y, ref, dtype, scale=1.0)
+    dy = rnd(130, 1936, dtype=dtype, seed=3)
+    y.backward(dy)
+    ref.backward(dy.float())
+    close(a.grad, af.grad, dtype, scale=4.0)
+    close(b.grad, bf.grad, dtype, scale=2.0)
+
+
 def test_ln_bwd_dropout_consistency(HF, Lb):
     """ProjResLn: dx_dropped must equal dx * (the GEMM epilogue's mask)."""
     M, N, K = 300, 256, 128

@@ -3,6 +3,7 @@
 
   python tools/profile_summary.py stats <dir-with-*_kernel_stats.csv> <micro-steps-in-trace> <out.csv> ["header note"]
   python tools/profile_summary.py pmc <fetch-dir> <write-dir> <out.json>
+  python tools/profile_summary.py mfma <pmc-dir> <out.json>
 
 `stats`: per-kernel calls / total ms / average us PER MICRO-STEP from `rocprofv3 --kernel-trace --stats`.
 `pmc`:  per-kernel average FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them; collected in two
@@ -65,8 +66,28 @@ def pmc(fd, wd, out):
     print("%d kernels -> %s" % (len(res), out))
 
 
+def mfma(d, out):
+    """MFMA utilisation per kernel from one --pmc pass with SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES and
+    GRBM_GUI_ACTIVE: busy cycles of the matrix pipes (summed over the chip's 1024 SIMDs; 32 per
+    v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md) / (4 SIMDs x 256 CUs x GPU-active cycles of the dispatch)."""
+    busy, act, cu = (_counter(d, "SQ_VALU_MFMA_BUSY_CYCLES"), _counter(d, "GRBM_GUI_ACTIVE"),
+                     _counter(d, "SQ_BUSY_CU_CYCLES"))
+    res = {}
+    for k, (n, tot) in busy.items():
+        if "hero::" not in k or k not in act or tot == 0:
+            continue
+        a = act[k][1] / act[k][0]
+        res[k] = {"launches": n, "SQ_VALU_MFMA_BUSY_CYCLES_avg": tot / n, "GRBM_GUI_ACTIVE_avg": a,
+                  "SQ_BUSY_CU_CYCLES_avg": cu[k][1] / cu[k][0] if k in cu else None,
+                  "mfma_util": tot / n / (1024.0 * a)}
+    json.dump(res, open(out, "w"), indent=1)
+    print("%d kernels -> %s" % (len(res), out))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "mfma":
+        mfma(*sys.argv[2:])
+    elif sys.argv[1] == "stats":
         stats(*sys.argv[2:])
     elif sys.argv[1] == "pmc":
         pmc(*sys.argv[2:])

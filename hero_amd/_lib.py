@@ -16,7 +16,7 @@ LAYOUT_K, LAYOUT_O = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
+    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
@@ -43,6 +43,11 @@ class CrossEntropy(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("labels", C.c_void_p), ("loss", C.c_void_p), ("lse", C.c_void_p),
                 ("dloss", C.c_void_p), ("dlogits", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
                 ("ld", C.c_int), ("dtype", C.c_int), ("inv_temp", C.c_float), ("ignore_index", C.c_int64)]
+
+
+class WgradProblem(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
+                ("ld_dy", C.c_int), ("ld_x", C.c_int), ("ld_dw", C.c_int), ("split_hint", C.c_int)]
 
 
 class LnFwd(C.Structure):
@@ -152,6 +157,7 @@ def lib():
         L.hero_colsum_workspace_bytes.restype = C.c_size_t
         L.hero_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [
             C.POINTER(GemmEpilogue), C.c_void_p]
+        L.hero_wgrad_group.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hero_prof_enable.argtypes = [C.c_int]
         L.hero_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_longlong)]

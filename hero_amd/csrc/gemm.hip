@@ -755,6 +755,8 @@ static ProfSlot g_prof[10];   // 0-7: (dtype, layouts) of the 4-wave kernels; 8 
 static bool g_prof_on = false;
 static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2,3), 8 / 9: wave-specialised kernels never / always; -1 = heuristic
 
+int gemm_forced_config() { return g_force_cfg; }
+
 struct ProfToken { ProfSlot* ps; hipEvent_t e0; };
 void* gemm_prof_begin(int slot, hipStream_t s) {
   if (!g_prof_on) return nullptr;

@@ -12,6 +12,8 @@ enum { EK_GENERIC = 0x100, EK_BIAS = 1, EK_GELU = 2, EK_RES = 4, EK_DROP = 8, EK
 void* gemm_prof_begin(int slot, hipStream_t s);
 void gemm_prof_end(void* token, double flops, hipStream_t s);
 
+int gemm_forced_config();     // hero_gemm_force_config state (gemm.hip): -1 heuristic, 8 = 4-wave kernels only, 9 = wave-specialised always
+
 // gemm_ws.hip.  Returns -1 when the problem is outside this kernel family (caller falls through to the
 // 4-wave kernels), otherwise the launch status.  C[M,N] (+)= op(A) op(B); see hero_gemm for the layouts.
 int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_layout,

@@ -478,6 +478,224 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped wgrad with a stream-K decomposition: up to 4 problems dW_p += dY_p^T X_p that reduce over the SAME rows
+// (the four weight gradients of a transformer layer: 64 + 64 + 16 + 48 = 192 tiles of 192 x 192 over 12000 rows) in
+// ONE launch.  The (tile, k-step) space of the whole group is cut into nwg equal contiguous ranges, one per
+// workgroup (256 x 140 tile-steps instead of four launches that each quantise to whole tiles x splits and each
+// end in their own merge tail).  A range covers the end of one tile and the beginning of the next (sometimes
+// a whole tile in between): each piece ("segment") is accumulated like an item of the kernel above - the loader
+// waves stream straight across the segment boundaries - and added to C with fp32 atomics (every tile receives
+// 1-3 partial sums).  Same tile geometry, ring, wave roles and O,O images as gemm_ws_kernel<3, 3, true>.
+// ------------------------------------------------------------------------------------------------
+struct WsgProb {
+  const bf16_t* A;      // dY  [K, lda], M columns from the pointer on
+  const bf16_t* B;      // X   [K, ldb], N columns
+  float* C;             // dW  [M, ldc]
+  int M, N, lda, ldb, ldc, tiles_n, tile0;     // tile0: index of this problem's first tile in the group order
+};
+struct WsgArgs {
+  WsgProb p[4];
+  int nprob, K, ksteps, total_tiles;
+};
+struct Seg { int prob, m0, n0, k0, nk; };
+
+template <typename G>
+__device__ __forceinline__ Seg seg_at(const WsgArgs& g, int pos, int end) {
+  const int tile = pos / g.ksteps, k0 = pos - tile * g.ksteps;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (q < g.nprob && tile >= g.p[q].tile0) pi = q;
+  const int t = tile - g.p[pi].tile0;
+  Seg s;
+  s.prob = pi;
+  s.m0 = (t / g.p[pi].tiles_n) * G::BM;
+  s.n0 = (t % g.p[pi].tiles_n) * G::BN;
+  s.k0 = k0;
+  s.nk = min(g.ksteps - k0, end - pos);
+  return s;
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wsg_kernel(WsgArgs g) {
+  typedef Geo<3, 3> G;
+  constexpr int TM = 3, TN = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const long long total = (long long)g.total_tiles * g.ksteps;
+  const int start = (int)(total * wg / nwg), end = (int)(total * (wg + 1) / nwg);
+  if (start >= end) return;                                          // uniform for the workgroup
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int w = wave - 4;
+    constexpr int CA = G::BM / 8, CB = G::BN / 8;
+    int pos = start;                 // next stage to issue belongs to the segment that contains `pos`
+    Seg sg = seg_at<G>(g, pos, end);
+    int ik = 0;
+    unsigned goa[G::PA], gob[G::PB];
+    const char* pa = nullptr;
+    const char* pb = nullptr;
+    unsigned ra_left = 0, rb_left = 0, sa = 0, sb = 0, fill = 0;
+    auto setup = [&]() {
+      const WsgProb& P = g.p[sg.prob];
+#pragma unroll
+      for (int i = 0; i < G::PA; ++i) {
+        const int id = (w * G::PA + i) * 64 + lane, row = id / CA, c = (id % CA) ^ swz_o<G::BM * 2>(row);
+        goa[i] = (unsigned)row * (unsigned)P.lda * 2u + (c << 4);
+      }
+#pragma unroll
+      for (int i = 0; i < G::PB; ++i) {
+        const int id = (w * G::PB + i) * 64 + lane, row = id / CB, c = (id % CB) ^ swz_o<G::BN * 2>(row);
+        gob[i] = (unsigned)row * (unsigned)P.ldb * 2u + (c << 4);
+      }
+      const int kb = sg.k0 * 64;
+      pa = reinterpret_cast<const char*>(P.A + (size_t)kb * P.lda + sg.m0);
+      pb = reinterpret_cast<const char*>(P.B + (size_t)kb * P.ldb + sg.n0);
+      ra_left = (unsigned)(((size_t)(g.K - kb) * P.lda - sg.m0) * 2);
+      rb_left = (unsigned)(((size_t)(g.K - kb) * P.ldb - sg.n0) * 2);
+      sa = 64u * (unsigned)P.lda * 2u;
+      sb = 64u * (unsigned)P.ldb * 2u;
+    };
+    setup();
+    auto issue = [&]() -> bool {
+      if (pos >= end) return false;
+      char* buf = smem + fill;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, ra_left, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, rb_left, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < G::PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < G::PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, 0);
+      fill += G::STAGE;
+      if (fill == NS * G::STAGE) fill = 0;
+      ++pos;
+      if (++ik == sg.nk) {
+        ik = 0;
+        if (pos < end) { sg = seg_at<G>(g, pos, end); setup(); }
+      } else {
+        pa += sa; pb += sb;
+        ra_left = ra_left > sa ? ra_left - sa : 0u;
+        rb_left = rb_left > sb ? rb_left - sb : 0u;
+      }
+      return true;
+    };
+    issue();
+    const bool second = issue();
+    if (second) wait_vm<G::PW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                                     // B(-1)
+    for (int u = start; u < end; ++u) {
+      if (issue()) wait_vm<G::PW>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();                                   // B(u)
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow0 = wm * TM * 32, brow0 = wn * TN * 32;
+  unsigned ao[TM], bo[TN];
+  {
+    const int p = lane & 15, gq = (lane >> 4) & 1, kg = lane >> 5;
+    const int krow = kg * 8 + (p >> 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int col = arow0 + i * 32 + gq * 16 + 4 * (p & 3);
+      ao[i] = krow * (G::BM * 2) + ((((col >> 3) ^ swz_o<G::BM * 2>(krow)) << 4) | ((col & 7) * 2));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = brow0 + j * 32 + gq * 16 + 4 * (p & 3);
+      bo[j] = G::A_BYTES + krow * (G::BN * 2) + ((((col >> 3) ^ swz_o<G::BN * 2>(krow)) << 4) | ((col & 7) * 2));
+    }
+  }
+  typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+  bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
+  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const char* q = st + ao[i] + ks * 16 * (G::BM * 2);
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BM * 2)));
+      a[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const char* q = st + bo[j] + ks * 16 * (G::BN * 2);
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BN * 2)));
+      b[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  f32x16_t acc[TM][TN];
+  auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_barrier();                                       // B(-1)
+  unsigned curo = 0;
+  ldf(a0, b0, smem, 0);
+  for (int pos = start; pos < end;) {
+    const Seg sg = seg_at<G>(g, pos, end);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int t = 0; t < sg.nk; ++t) {
+      const char* cur = smem + curo;
+      curo += G::STAGE;
+      if (curo == NS * G::STAGE) curo = 0;
+      const char* nxt = smem + curo;
+      ldf(a1, b1, cur, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a0, b0, cur, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a1, b1, cur, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds();
+      __builtin_amdgcn_s_barrier();                                   // B(u)
+      __builtin_amdgcn_sched_barrier(0);
+      if (pos + t + 1 < end) ldf(a0, b0, nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pos += sg.nk;
+    const WsgProb& P = g.p[sg.prob];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int gn = sg.n0 + brow0 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gm = sg.m0 + arow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (gm < P.M && gn < P.N) atomicAdd(P.C + (size_t)gm * P.ldc + gn, acc[i][j][r]);
+        }
+      }
+  }
+}
+
 // explicit instantiations (hipcc does not emit the host stubs of kernels that are only reached through two
 // levels of host-side templates)
 #define HERO_WS_INST(TM, TN)                                                                  \
@@ -609,3 +827,55 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
 }
 
 }  // namespace hero
+
+// dW_p += dY_p^T X_p for up to 4 problems over the same K rows, one stream-K launch (hero_hip.h).
+extern "C" int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int dtype, hero_stream_t stream) {
+  using namespace hero;
+  using namespace hero::ws;
+  HERO_REQUIRE(probs && n >= 1 && n <= 4, "hero_wgrad_group: 1..4 problems");
+  HERO_REQUIRE(dtype == HERO_BF16 || dtype == HERO_F32, "hero_wgrad_group: bad dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  typedef Geo<3, 3> G;
+  bool ok = dtype == HERO_BF16 && K >= 64 * 16 && gemm_forced_config() != 8;
+  WsgArgs g;
+  int tiles = 0;
+  for (int i = 0; i < n && ok; ++i) {
+    const HeroWgradProblem& q = probs[i];
+    HERO_REQUIRE(q.dy && q.x && q.dw && q.M > 0 && q.N > 0, "hero_wgrad_group: bad problem %d", i);
+    ok = ok && q.M % 8 == 0 && q.N % 8 == 0 && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dw % 4 == 0 &&
+         (((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dw) & 15) == 0 &&
+         (size_t)K * q.ld_dy * 2 < 0xffffffffull && (size_t)K * q.ld_x * 2 < 0xffffffffull;
+    WsgProb& P = g.p[i];
+    P.A = static_cast<const bf16_t*>(q.dy); P.B = static_cast<const bf16_t*>(q.x); P.C = q.dw;
+    P.M = q.M; P.N = q.N; P.lda = q.ld_dy; P.ldb = q.ld_x; P.ldc = q.ld_dw;
+    P.tiles_n = (q.N + G::BN - 1) / G::BN;
+    P.tile0 = tiles;
+    tiles += ((q.M + G::BM - 1) / G::BM) * P.tiles_n;
+  }
+  const int ksteps = (K + 63) / 64;
+  const int cus = num_cus();
+  if (ok && (long long)tiles * ksteps >= 8LL * cus) {
+    for (int i = n; i < 4; ++i) g.p[i] = g.p[0];
+    g.nprob = n; g.K = K; g.ksteps = ksteps; g.total_tiles = tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+      attr_set = true;
+    }
+    double flops = 0.0;
+    for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * K;
+    void* tok = gemm_prof_begin(9, s);
+    hipLaunchKernelGGL(gemm_wsg_kernel, dim3(cus), dim3(512), G::LDS, s, g);
+    gemm_prof_end(tok, flops, s);
+    return check_launch("hero_wgrad_group");
+  }
+  // outside the kernel's envelope: one hero_gemm per problem (accumulate)
+  for (int i = 0; i < n; ++i) {
+    const HeroWgradProblem& q = probs[i];
+    HeroGemmEpilogue e = {};
+    e.out_f32 = 1; e.beta = 1.f; e.split_k = q.split_hint > 0 ? q.split_hint : 1; e.dropout.scale = 1.f;
+    const int rc = hero_gemm(q.dy, q.x, q.dw, q.M, q.N, K, q.ld_dy, q.ld_x, q.ld_dw, HERO_LAYOUT_O, HERO_LAYOUT_O, dtype, &e, stream);
+    if (rc) return rc;
+  }
+  return HERO_OK;
+}

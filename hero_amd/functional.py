@@ -11,6 +11,7 @@ Block structure (one autograd node each, residual fan-in fused into GEMM epilogu
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -43,7 +44,8 @@ class _Rng:
         self.site = 0
 
     def seed_tensor(self, device):
-        key = (device.type, device.index)
+        idx = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else None)
+        key = (device.type, idx)            # "cuda" and "cuda:0" are the same seed word
         t = self.seeds.get(key)
         if t is None:
             t = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64,
@@ -336,17 +338,58 @@ def _split_for(n_out, n_in, rows, bk):
     return best
 
 
-def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None):
+# Weight gradients that ACCUMULATE into the gradient sink are not launched one by one: inside a backward pass they
+# are queued and launched four at a time - the four nn.Linear weights of a BertLayer reduce over the same rows -
+# as ONE stream-K launch (hero_wgrad_group).  The queue is flushed when it holds four problems, when the row count
+# changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
+# pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
+_WQ = []
+GROUP_WGRADS = [os.environ.get("HERO_NOGROUP", "") == ""]      # HERO_NOGROUP=1: one launch per weight gradient (A/B runs)
+
+
+def wgrad_flush():
+    while _WQ:
+        rows, dtype = _WQ[0][0].shape[0], _WQ[0][0].dtype
+        n = 1
+        while n < len(_WQ) and n < 4 and _WQ[n][0].shape[0] == rows and _WQ[n][0].dtype == dtype:
+            n += 1
+        group, rest = _WQ[:n], _WQ[n:]
+        del _WQ[:]
+        _WQ.extend(rest)
+        probs = (L.WgradProblem * n)()
+        for i, (dy2, x2, out, col0, N, _) in enumerate(group):
+            K = x2.shape[1]
+            probs[i] = L.WgradProblem(L.ptr(dy2) + col0 * dy2.element_size(), L.ptr(x2), L.ptr(out), N, K,
+                                      dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32))
+        L.check(L.lib().hero_wgrad_group(probs, n, rows, L.dt(group[0][0]), L.stream()))
+        for e in group:
+            if e[5] is not None:
+                e[5]()
+
+
+def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
     """dW[N,K] (fp32) = beta*dW + dy2[:, col0:col0+N]^T @ x2[M,K]."""
     M, ld = dy2.shape
     N = ld - col0 if ncols is None else ncols
     K = x2.shape[1]
+    if (out is not None and beta == 1.0 and GROUP_WGRADS[0] and out.is_contiguous() and dy2.is_contiguous()
+            and x2.is_contiguous() and torch._C._current_graph_task_id() != -1):
+        if _WQ and (_WQ[0][0].shape[0] != M or _WQ[0][0].dtype != dy2.dtype):
+            wgrad_flush()
+        if not _WQ:
+            torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
+        _WQ.append((dy2, x2, out, col0, N, on_done))
+        if len(_WQ) == 4:
+            wgrad_flush()
+        return out
     if out is None:
         out = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
     split = _split_for(N, K, M, 64 if dy2.dtype == torch.bfloat16 else 32)
     a = L.ptr(dy2) + col0 * dy2.element_size()
     k_gemm(a, x2, out, N, K, M, ld, K, K, L.LAYOUT_O, L.LAYOUT_O, L.dt(dy2), out_f32=True,
            beta=beta, split_k=split)
+    if on_done is not None:
+        on_done()
     return out
 
 
@@ -377,8 +420,7 @@ def acc_linear_grads(dy2, x2, weight, bias, col0=0, ncols=None):
     """weight.grad += dy^T x ; bias.grad += colsum(dy) straight into the gradient sink."""
     N = ncols if ncols is not None else weight.shape[0]
     if weight is not None and weight.requires_grad:
-        k_wgrad(dy2, x2, out=SINK.dst(weight), beta=1.0, col0=col0, ncols=N)
-        SINK.done(weight)
+        k_wgrad(dy2, x2, out=SINK.dst(weight), beta=1.0, col0=col0, ncols=N, on_done=lambda: SINK.done(weight))
     if bias is not None and bias.requires_grad:
         k_colsum(dy2, out=SINK.dst(bias), beta=1.0, col0=col0, ncols=N)
         SINK.done(bias)
@@ -821,13 +863,13 @@ def _qkv_bwd(dqkv, x2, qkv_params, D):
     gw = SINK.dst_group(ws) if all(p.requires_grad for p in ws) else None
     gb = SINK.dst_group(bs) if all(p.requires_grad for p in bs) else None
     if gw is not None:
-        k_wgrad(dqkv, x2, out=gw, beta=1.0)
+        k_wgrad(dqkv, x2, out=gw, beta=1.0, on_done=lambda: [SINK.done(p) for p in ws])
     if gb is not None:
         k_colsum(dqkv, out=gb.view(-1), beta=1.0)
     for i, (w, b) in enumerate(zip(ws, bs)):
         acc_linear_grads(dqkv, x2, None if gw is not None else w, None if gb is not None else b, col0=i * D,
                          ncols=D)
-    for p in (ws if gw is not None else ()) + (bs if gb is not None else ()):
+    for p in (bs if gb is not None else ()):
         SINK.done(p)
 
 

@@ -88,6 +88,18 @@ int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
  * roofline leg; off by default, never enable inside graph capture).
  * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout for the 4-wave kernels, 8 / 9 for the
  * wave-specialised K,K / O,O kernels (gemm_ws.hip). hero_prof_read synchronises. */
+/* Grouped weight gradient: dw_p[M_p, N_p] (fp32) += dy_p[K, :M_p]^T x_p[K, :N_p] for 1..4 problems that reduce over
+ * the same K rows - the four nn.Linear weights of a BertLayer (model/layers.py:125-127, 176, 237, 251) - in ONE
+ * launch (stream-K over the (tile, k) space of the whole group, fp32 atomics into dw).  Small / unaligned / fp32
+ * groups run as one hero_gemm per problem (split_hint = its split_k). */
+typedef struct HeroWgradProblem {
+  const void* dy;   /* [K, ld_dy] dtype, the M columns starting at this pointer */
+  const void* x;    /* [K, ld_x] dtype                                          */
+  float* dw;        /* [M, ld_dw] fp32, accumulated                            */
+  int M, N, ld_dy, ld_x, ld_dw;
+  int split_hint;
+} HeroWgradProblem;
+int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int dtype, hero_stream_t stream);
 int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
                                       * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
                                       * bits 8+: M-tiles per L2 locality group; -1 heuristic */

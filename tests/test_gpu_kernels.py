@@ -170,6 +170,56 @@ def test_gemm_wave_specialised_wgrad(HF, Lb, rows, n_out, n_in):
     torch.testing.assert_close(half, ref[n_out // 2 // 8 * 8:], **tol)
 
 
+@pytest.mark.parametrize("rows", [12000, 12040, 1920, 520])
+def test_wgrad_group_stream_k(HF, Lb, rows):
+    """hero_wgrad_group: the four weight gradients of a BertLayer (QKV 2304x768, out 768x768, FFN1 3072x768, FFN2
+    768x3072) over the same rows in ONE stream-K launch, accumulated into existing values; the reduction tail
+    (rows % 64 != 0), a column-sliced dY, and the small-problem fallback (one hero_gemm per problem)."""
+    import ctypes as C
+    dtype = torch.bfloat16
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+    dys = [rnd(rows, n, dtype=dtype, seed=10 + i) for i, (n, _) in enumerate(shapes)]
+    xs = [rnd(rows, k, dtype=dtype, seed=20 + i) for i, (_, k) in enumerate(shapes)]
+    outs = [torch.full((n, k), 0.5, device="cuda") for n, k in shapes]
+    probs = (Lb.WgradProblem * 4)()
+    for i, (n, k) in enumerate(shapes):
+        probs[i] = Lb.WgradProblem(dys[i].data_ptr(), xs[i].data_ptr(), outs[i].data_ptr(), n, k, n, k, k, 4)
+    Lb.check(Lb.lib().hero_wgrad_group(probs, 4, rows, Lb.BF16, Lb.stream()))
+    for i in range(4):
+        ref = dys[i].float().t() @ xs[i].float() + 0.5
+        torch.testing.assert_close(outs[i], ref, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    # two problems, the first one a column slice of a wider dY (the per-tensor path of the fused QKV gradient)
+    out2 = [torch.zeros(768, 768, device="cuda"), torch.zeros(768, 3072, device="cuda")]
+    p2 = (Lb.WgradProblem * 2)()
+    p2[0] = Lb.WgradProblem(dys[0].data_ptr() + 768 * 2, xs[0].data_ptr(), out2[0].data_ptr(), 768, 768, 2304, 768, 768, 4)
+    p2[1] = Lb.WgradProblem(dys[3].data_ptr(), xs[3].data_ptr(), out2[1].data_ptr(), 768, 3072, 768, 3072, 3072, 4)
+    Lb.check(Lb.lib().hero_wgrad_group(p2, 2, rows, Lb.BF16, Lb.stream()))
+    torch.testing.assert_close(out2[0], dys[0].float()[:, 768:1536].t() @ xs[0].float(), rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    torch.testing.assert_close(out2[1], dys[3].float().t() @ xs[3].float(), rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+
+
+def test_deferred_weight_gradients_are_flushed_with_the_backward_pass(HF, Lb):
+    """Sink-accumulated weight gradients are queued during backward and launched in groups; whoever looks at a
+    .grad after backward() sees the complete sum, whatever the number of queued problems."""
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(n, 768, device="cuda") * 0.02) for n in (768, 1536, 768, 768, 2304)]
+    x = rnd(4096, 768, dtype=torch.bfloat16, seed=1)
+    y = x
+    for w in ws:                                       # five chained Linear layers: 4 + 1 queued problems
+        y = HF.linear(y, w)
+        y = y[:, :768].contiguous()
+    y.float().pow(2).sum().backward()
+    ref_ws = [w.detach().clone().requires_grad_(True) for w in ws]
+    yr = x.float()
+    for w in ref_ws:
+        yr = (yr @ w.to(torch.bfloat16).float().t())[:, :768]
+        yr = yr.to(torch.bfloat16).float()
+    yr.pow(2).sum().backward()
+    for w, r in zip(ws, ref_ws):
+        assert w.grad is not None
+        torch.testing.assert_close(w.grad, r.grad, rtol=5e-2, atol=5e-2 * float(r.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(700, 776, 768), (12000, 3072, 768), (130, 64, 64)])
 def test_gemm_output_column_sums(HF, Lb, dtype, M, N, K):

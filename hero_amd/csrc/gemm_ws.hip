@@ -46,6 +46,16 @@ constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// output stores of the K,K epilogue (A/B hook: -DHERO_WS_NT_STORE streams them past the L2)
+__device__ __forceinline__ void st_out(uint4* p, uint4 v) {
+#ifdef HERO_WS_NT_STORE
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
+#else
+  *p = v;
+#endif
+}
+
 struct WsArgs {
   const void* A;
   const void* B;
@@ -258,7 +268,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
         if (EK & EK_GELU) {
           uint4 u;
           u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
-          if (ok[it]) *reinterpret_cast<uint4*>(X + off[it]) = u;
+          if (ok[it]) st_out(reinterpret_cast<uint4*>(X + off[it]), u);
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
         }
@@ -292,7 +302,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
         }
         uint4 o;
         o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
-        if (ok[it]) *reinterpret_cast<uint4*>(Cb + off[it]) = o;
+        if (ok[it]) st_out(reinterpret_cast<uint4*>(Cb + off[it]), o);
       }
     }
     wait_lds();

@@ -344,6 +344,7 @@ def _split_for(n_out, n_in, rows, bk):
 # changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
 # pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
 _WQ = []
+_WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [os.environ.get("HERO_NOGROUP", "") == ""]      # HERO_NOGROUP=1: one launch per weight gradient (A/B runs)
 
 
@@ -374,9 +375,13 @@ def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
     K = x2.shape[1]
     if (out is not None and beta == 1.0 and GROUP_WGRADS[0] and out.is_contiguous() and dy2.is_contiguous()
             and x2.is_contiguous() and torch._C._current_graph_task_id() != -1):
+        task = torch._C._current_graph_task_id()
+        if _WQ and _WQ_TASK[0] != task:
+            del _WQ[:]                  # left behind by a backward pass that raised: never launch them into this one
         if _WQ and (_WQ[0][0].shape[0] != M or _WQ[0][0].dtype != dy2.dtype):
             wgrad_flush()
         if not _WQ:
+            _WQ_TASK[0] = task
             torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
         _WQ.append((dy2, x2, out, col0, N, on_done))
         if len(_WQ) == 4:

@@ -195,6 +195,11 @@ class GradArena(HF.GradSink):
             # something replaced .grad (e.g. zero_grad(set_to_none=True)); fold it back
             self.flat[sl[0]:sl[1]].add_(p.grad.reshape(-1))
             p.grad = self.flat[sl[0]:sl[1]].view_as(p)
+        if self._uses.get(p, 0) > 0:
+            # a parameter of the HIP backward (registered by `use`): AccumulateGrad - and this hook - also runs when the
+            # node returns no gradient for it.  Its finality is `done`'s call, which may come LATER than the node
+            # (weight gradients are queued and launched in groups, functional.k_wgrad): do not count it here.
+            return
         self._on_final(p)
 
     def _on_final(self, p):

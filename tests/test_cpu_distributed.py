@@ -176,6 +176,59 @@ def test_grad_arena_intermittent_parameter():
     assert all(spawn(_arena_intermittent))
 
 
+def _arena_deferred_done(rank, world):
+    """Weight gradients of the HIP backward are queued and launched in groups AFTER their autograd node returned
+    (functional.k_wgrad): the arena must take a sink parameter's finality from `done`, not from the AccumulateGrad
+    hook that fires when the node returns (found by the 2-rank GPU test: buckets were reduced before the queued
+    launch had run)."""
+    from hero_amd import functional as HF
+    from hero_amd.utils import distributed as D
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(6, 6))
+    v = torch.nn.Parameter(torch.randn(6))
+    arena = D.GradArena([w, v], bucket_bytes=1 << 20, overlap=True)
+    seen = {}
+
+    class LateSink(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, wt):
+            HF.SINK.use(wt)
+            ctx.save_for_backward(x)
+            ctx.w = wt
+            return x @ wt.detach()
+
+        @staticmethod
+        def backward(ctx, dy):
+            (x,) = ctx.saved_tensors
+            wt = ctx.w
+
+            def later():                                   # the "grouped launch" at the end of the backward pass
+                seen["launched_before"] = list(arena._launched)
+                HF.SINK.dst(wt).add_(x.t() @ dy)
+                HF.SINK.done(wt)
+            torch.autograd.Variable._execution_engine.queue_callback(later)
+            return dy @ wt.detach().t(), None
+
+    arena.set_sync(True)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(40 + rank), requires_grad=True)
+    (LateSink.apply(x, w) * v).sum().backward()
+    launched_in_backward = sum(arena._launched)
+    arena.finish()
+    want = 0
+    for r in range(world):
+        xr = torch.randn(4, 6, generator=torch.Generator().manual_seed(40 + r))
+        a = w.detach().clone().requires_grad_()
+        ((xr @ a) * v.detach()).sum().backward()
+        want = want + a.grad
+    ok = seen["launched_before"] == [False] and launched_in_backward == 1 and torch.allclose(w.grad, want, atol=1e-5)
+    HF.set_grad_sink(None)
+    return bool(ok)
+
+
+def test_grad_arena_finality_of_queued_weight_gradients():
+    assert all(spawn(_arena_deferred_done))
+
+
 def _arena_bf16_wire(rank, world):
     """compress='bf16': the buckets are summed in bf16 on the wire (the reference's fp16 payload) and widened
     back into the fp32 arena; the result is the bf16-rounded sum of the bf16-rounded local gradients."""

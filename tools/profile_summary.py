@@ -69,7 +69,9 @@ def pmc(fd, wd, out):
 def mfma(d, out):
     """MFMA utilisation per kernel from one --pmc pass with SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES and
     GRBM_GUI_ACTIVE: busy cycles of the matrix pipes (summed over the chip's 1024 SIMDs; 32 per
-    v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md) / (4 SIMDs x 256 CUs x GPU-active cycles of the dispatch)."""
+    v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md) / (4 SIMDs x 256 CUs x GPU-active cycles of the dispatch).
+    rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs (checked: value / 8 / kernel duration = 2.2-2.3 GHz, and the busy
+    cycles equal 32 x the kernel's MFMA count), hence the division by 8."""
     busy, act, cu = (_counter(d, "SQ_VALU_MFMA_BUSY_CYCLES"), _counter(d, "GRBM_GUI_ACTIVE"),
                      _counter(d, "SQ_BUSY_CU_CYCLES"))
     res = {}
@@ -79,7 +81,7 @@ def mfma(d, out):
         a = act[k][1] / act[k][0]
         res[k] = {"launches": n, "SQ_VALU_MFMA_BUSY_CYCLES_avg": tot / n, "GRBM_GUI_ACTIVE_avg": a,
                   "SQ_BUSY_CU_CYCLES_avg": cu[k][1] / cu[k][0] if k in cu else None,
-                  "mfma_util": tot / n / (1024.0 * a)}
+                  "gpu_active_cycles": a / 8.0, "mfma_util": tot / n / (1024.0 * a / 8.0)}
     json.dump(res, open(out, "w"), indent=1)
     print("%d kernels -> %s" % (len(res), out))
 

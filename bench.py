@@ -133,7 +133,7 @@ def _timed(trainer, batch, task, steps, warmup, world):
     """prepare (untimed) + warm-up + `steps` micro-steps bracketed by barrier + synchronise; max over ranks."""
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
             torch.cuda.synchronize()
     trainer.prepare(batch, task)
@@ -157,7 +157,7 @@ def secondary_workload(args, device, world, rank):
     from hero_amd.step import TrainStep
     from hero_amd.synth import SHAPES, make_batch, make_pretrain_batches
     cfg = json.loads(json.dumps(HERO_BASE))
-    graph = world == 1 and not args.no_graph
+    graph = not torch.distributed.is_initialized() and not args.no_graph
     steps, warmup = args.steps + args.steps % 2, args.warmup + args.warmup % 2     # whole accumulation windows
     base = {"unit": "videos/s", "n_gpus": world, "steps": steps, "warmup": warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32",
@@ -284,7 +284,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or (bool(os.environ.get("HERO_DP_FORCE_COLLECTIVES")) and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("HERO_BENCH_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -299,21 +300,21 @@ def main():
     hero_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     if args.workload != "D2":
         secondary_workload(args, device, world, rank)
-        if world > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return
     cfg_path = "/tmp/hero_finetune_bench_%d.json" % rank
     with open(cfg_path, "w") as f:
         json.dump(HERO_BASE, f)
     model = build_model(device, cfg_path)
-    trainer = TrainStep(model, use_graph=(world == 1 and not args.no_graph),
+    trainer = TrainStep(model, use_graph=(not dist_on and not args.no_graph),
                         static_usage=True)     # drop_svmr_prob = 0: every step uses the same parameters
     batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device)
     sh = SHAPES["D2"]
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -326,7 +327,7 @@ def main():
         loss = trainer.micro_step(batch)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -372,7 +373,7 @@ def main():
     elif world > 1:
         for _ in range(args.profile_steps):
             trainer.micro_step(batch)
-    launch_mode = "hipGraph replay" if (world == 1 and not args.no_graph) else "eager"
+    launch_mode = "hipGraph replay" if (not dist_on and not args.no_graph) else "eager"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -399,7 +400,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

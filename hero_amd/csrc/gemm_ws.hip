@@ -17,6 +17,11 @@
 // The 192 x 192 tile is the shape of the step: M = 12000 rows and N = 768 k give 63 x 4 k tiles = 252 k
 // workgroups on 256 CUs (98 % fill for N = 768, 2304, 3072; 256 x 256 tiles fill 55 % of one round at N = 768).
 //
+// (Tried and dropped, round 2: the same tile with 4 waves that load AND compute, 32-k stages, two workgroups per
+// CU so that one's epilogue overlaps the other's main loop - 69 vs 55 us at N = 768, K = 3072 and 73 vs 67 us at
+// N = 3072, K = 768.  A 6-stage ring (120 KiB in flight) ran at the same 0.72 us per 32-k step as the 3-stage one:
+// not load latency but the VMEM issue slots inside the MFMA stream, which is what the loader waves remove.)
+//
 // Epilogue, K,K: accumulators -> LDS (fp32, the ring slot that was read last, 64 rows per pass, 16-byte
 // chunks XOR-swizzled by row) -> all 8 waves apply bias / GELU / dropout / residual / gelu' on full rows
 // and store 16 B per lane.  The MFMA operands are swapped (D^T = B A^T) so that a lane holds 4

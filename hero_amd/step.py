@@ -52,11 +52,11 @@ class TrainStep:
         self.optimizer = build_optimizer(model, self.opts)
         self.arena = D.GradArena(list(model.parameters()), bucket_bytes=bucket_bytes,
                                  groups=qkv_groups(model), static_usage=static_usage,
-                                 compress=grad_compress if D.world_size() > 1 else None)
+                                 compress=grad_compress if D.collectives_active() else None)
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152
-        self.use_graph = use_graph and D.world_size() == 1
+        self.use_graph = use_graph and not D.collectives_active()
         self._graphs = {}             # task -> (plain graph, its loss, boundary graph, its loss, static batch)
         self._window = []             # tasks of the micro-steps accumulated since the last optimiser step
         # compute copies of the weights are cached per optimiser step: anything else that rewrites parameters

@@ -11,6 +11,8 @@ MI355X-first additions: GradArena keeps all gradients in ONE flat fp32 buffer th
 accumulates into in place, so buckets are all-reduced straight out of it (no flatten/unflatten
 copies) and are launched from autograd hooks while the rest of backward is still running.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,6 +29,13 @@ def world_size():
 
 def rank():
     return dist.get_rank() if _on() else 0
+
+
+def collectives_active():
+    """True when gradient buckets really travel through torch.distributed: more than one rank, or an initialised
+    1-rank group with HERO_DP_FORCE_COLLECTIVES=1 (how the RCCL path - init, comm-stream ordering, bf16 wire - is
+    exercised on a 1-GPU box, tests/test_gpu_distributed.py)."""
+    return _on() and (dist.get_world_size() > 1 or bool(os.environ.get("HERO_DP_FORCE_COLLECTIVES")))
 
 
 # ---- gradient averaging (utils/distributed.py:19-46) -----------------------------------------
@@ -207,7 +216,7 @@ class GradArena(HF.GradSink):
         if p in self._final or p not in self.bucket_of:
             return
         self._final.add(p)
-        if not (self.sync and self.overlap) or world_size() == 1:
+        if not (self.sync and self.overlap) or not collectives_active():
             return
         b = self.bucket_of[p]
         if self._expect is not None and p not in self._expect:
@@ -249,7 +258,7 @@ class GradArena(HF.GradSink):
 
     def finish(self):
         """Issue all-reduces for buckets the hooks did not complete, then wait for everything."""
-        if world_size() > 1 and self.sync:
+        if collectives_active() and self.sync:
             for b in range(len(self.buckets)):
                 self._launch(b)
             for h, b in self._handles:
@@ -372,4 +381,4 @@ def any_broadcast(data, root_rank):
 
 
 __all__ = ["all_reduce_and_rescale_tensors", "broadcast_tensors", "GradArena", "gather_negatives",
-           "all_gather_list", "any_broadcast", "world_size", "rank"]
+           "all_gather_list", "any_broadcast", "world_size", "rank", "collectives_active"]

@@ -1,8 +1,10 @@
-"""Worker of tests/test_gpu_distributed.py: one rank of a 2-process data-parallel run with the REAL
-HIP kernels.  The GPU box has one MI355X, so both ranks use cuda:0 and the collectives go through
-gloo (host-staged) instead of RCCL; everything above the transport - GradArena's use/done counting
-from the HIP backward, bucket launches, averaging folded into the optimiser, cross-rank negatives -
-is the production code path of bench.py --gpus N."""
+"""Worker of tests/test_gpu_distributed.py: one rank of a data-parallel run with the REAL HIP kernels.
+The GPU box has one MI355X, so either (a) two ranks share cuda:0 and the collectives go through gloo
+(host-staged) - everything above the transport (GradArena's use/done counting from the HIP backward,
+bucket launches, averaging folded into the optimiser, cross-rank negatives) is the production code path
+of bench.py --gpus N - or (b) ONE rank runs over the real RCCL backend with HERO_DP_FORCE_COLLECTIVES=1:
+process-group setup on the device, asynchronous all-reduces on RCCL's stream while backward continues,
+the bf16 wire buffers, wait / barrier / teardown."""
 import json
 import os
 import sys
@@ -19,7 +21,11 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
     import hero_amd
     from hero_amd import functional as HF
     from hero_amd.step import TrainStep
@@ -44,7 +50,7 @@ def main():
     chk = torch.stack([p.detach().double().sum() for p in named.values()])
     both = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(both, chk)
-    assert torch.equal(both[0], both[1]), "parameter broadcast failed"
+    assert all(torch.equal(both[0], b) for b in both), "parameter broadcast failed"
 
     batch = make_batch("D1", vfeat_dim=96, vocab=160, seed=1 + rank, device=dev)
     errs = []
@@ -59,7 +65,7 @@ def main():
         local = trainer.arena.flat.clone()
         gl = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gl, local)
-        want_sum = gl[0] + gl[1]
+        want_sum = sum(gl)
         # (3) the same two micro-steps through the production path: buckets all-reduced from the hooks
         trainer.arena.zero()
         trainer.arena.set_sync(False)
@@ -89,9 +95,11 @@ def main():
     chk = torch.stack([p.detach().double().sum() for p in named.values()])
     both = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(both, chk)
-    assert torch.equal(both[0], both[1]), "replicas diverged after optimiser steps"
+    assert all(torch.equal(both[0], b) for b in both), "replicas diverged after optimiser steps"
     assert all(l == l and abs(l) < 1e4 for l in losses)
-    json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses},
+    torch.cuda.synchronize()
+    json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses, "backend": dist.get_backend(),
+               "collectives": bool(__import__("hero_amd.utils.distributed", fromlist=["x"]).collectives_active())},
               open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
     dist.destroy_process_group()
 

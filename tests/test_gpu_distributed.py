@@ -42,3 +42,33 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 64 and out["config"]["launch"] == "eager"
     assert out["final_loss"] == out["final_loss"] and out["roofline"]["frac"] > 0      # finite loss, GEMM events recorded
+
+
+@pytest.mark.parametrize("wire", ["none", "bf16"])
+def test_one_rank_over_rccl(tmp_path, wire):
+    """The real RCCL backend (`init_process_group("nccl", device_id=...)`) with one rank and
+    HERO_DP_FORCE_COLLECTIVES=1: every gradient bucket goes through an asynchronous RCCL all-reduce issued from the
+    backward hooks (fp32 in place / bf16 wire buffers), finish() waits on RCCL's stream, the optimiser follows."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), wire, "nccl"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(tmp_path / "rank0.json"))
+    assert res["backend"] == "nccl" and res["collectives"] and res["buckets"] > 3
+
+
+def test_bench_one_rank_over_rccl():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, eager launches, RCCL process group, bucketed
+    bf16 all-reduce overlapped with backward), with the one rank a 1-GPU box can host."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["launch"] == "eager" and out["value"] > 0
+    assert out["final_loss"] == out["final_loss"]
+    print("bench over RCCL (1 rank, eager, forced collectives):", out["value"], "videos/s", out["ms_per_step"], "ms")

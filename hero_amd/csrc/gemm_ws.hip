@@ -51,6 +51,18 @@ constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+#ifdef HERO_WS_TRACE
+// timeline probe (tools/lab/ws_trace.py): s_memtime stamps of the first four items of workgroup 0, per wave
+__device__ unsigned long long g_ws_trace[4 * 16 * 8];
+#define WS_T(item_no, ev, wave, lane)                                                                   \
+  do {                                                                                                  \
+    if (blockIdx.x == 0 && (lane) == 0 && (item_no) >= 0 && (item_no) < 4)                              \
+      g_ws_trace[((item_no) * 16 + (ev)) * 8 + (wave)] = __builtin_readcyclecounter();                  \
+  } while (0)
+#else
+#define WS_T(item_no, ev, wave, lane) do { } while (0)
+#endif
+
 // output stores of the K,K epilogue (A/B hook: -DHERO_WS_NT_STORE streams them past the L2)
 __device__ __forceinline__ void st_out(uint4* p, uint4 v) {
 #ifdef HERO_WS_NT_STORE
@@ -200,7 +212,7 @@ struct Loader {
 // ------------------------------------------------------------------------------------------------
 template <typename G, int EK, bool COMPUTE>
 __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, char* smem, unsigned slot, f32x16_t (*acc)[G::TN], int wave,
-                                              int lane) {
+                                              int lane, int trace_item = -1) {
   constexpr int TM = G::TM, TN = G::TN, BN = G::BN, RPP = G::RPP, C8 = G::C8, RPI = G::RPI, ITERS = G::ITERS;
   const HeroGemmEpilogue& e = g.epi;
   char* st = smem + slot;
@@ -241,6 +253,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
       if (EK & EK_RES) pre[it] = *reinterpret_cast<const uint4*>(R + off[it]);
       if (EK & EK_GELU_BWD) pre[it] = *reinterpret_cast<const uint4*>(X + off[it]);
     }
+    WS_T(trace_item, 2 + 4 * p, wave, lane);
     if constexpr (COMPUTE) {
 #pragma unroll
       for (int b = 0; b < RPP / 32; ++b) {
@@ -259,7 +272,9 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
       }
     }
     wait_lds();
+    WS_T(trace_item, 3 + 4 * p, wave, lane);
     __builtin_amdgcn_s_barrier();                    // E1: the pass is staged
+    WS_T(trace_item, 4 + 4 * p, wave, lane);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int row = r0 + it * RPI;
@@ -311,8 +326,10 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
       }
     }
     wait_lds();
+    WS_T(trace_item, 5 + 4 * p, wave, lane);
     __builtin_amdgcn_s_barrier();                    // E2: the slot may be restaged / refilled
   }
+  WS_T(trace_item, 14, wave, lane);
   if (EK & EK_GELU_BWD) {                            // uniform across the workgroup (kernel argument)
     if (e.colsum != nullptr) {
       float* sp = reinterpret_cast<float*>(smem + SPARE_OFF);
@@ -357,14 +374,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (second) wait_vm<G::PW>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                                     // B(-1): stage 0 landed
     unsigned slot = 0;
-    for (int cit = wg; cit < g.nwork; cit += nwg) {
+    int item_no = 0;
+    for (int cit = wg; cit < g.nwork; cit += nwg, ++item_no) {
       const Item ic = item_coord<G>(g, cit);
+      WS_T(item_no, 0, wave, lane);
       for (int t = 0; t < ic.nk; ++t) {
         if (ld.issue()) wait_vm<G::PW>(); else wait_vm<0>();          // stage u+2 issued, stage u+1 landed
         __builtin_amdgcn_s_barrier();                                 // B(u)
         if (t + 1 < ic.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
       }
-      if constexpr (!TR) epilogue_rows<G, EK, false>(g, ic, smem, slot, nullptr, wave, lane);
+      WS_T(item_no, 1, wave, lane);
+      if constexpr (!TR) epilogue_rows<G, EK, false>(g, ic, smem, slot, nullptr, wave, lane, item_no);
       slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0;
     }
     return;
@@ -434,8 +454,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_barrier();                                       // B(-1)
   unsigned curo = 0;
   if (wg < g.nwork) ldf(a0, b0, smem, 0);
-  for (int cit = wg; cit < g.nwork; cit += nwg) {
+  int item_no = 0;
+  for (int cit = wg; cit < g.nwork; cit += nwg, ++item_no) {
     const Item ic = item_coord<G>(g, cit);
+    WS_T(item_no, 0, wave, lane);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -472,7 +494,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if constexpr (!TR) {
       __builtin_amdgcn_s_setprio(0);
-      epilogue_rows<G, EK, true>(g, ic, smem, last, acc, wave, lane);
+      WS_T(item_no, 1, wave, lane);
+      epilogue_rows<G, EK, true>(g, ic, smem, last, acc, wave, lane, item_no);
       __builtin_amdgcn_s_setprio(2);
       if (more_items) ldf(a0, b0, smem + curo, 0);
     } else {
@@ -842,6 +865,12 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
 }
 
 }  // namespace hero
+
+#ifdef HERO_WS_TRACE
+extern "C" int hero_ws_trace_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hero::ws::g_ws_trace), sizeof(unsigned long long) * 4 * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // dW_p += dY_p^T X_p for up to 4 problems over the same K rows, one stream-K launch (hero_hip.h).
 extern "C" int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int dtype, hero_stream_t stream) {

@@ -22,6 +22,13 @@
 // N = 3072, K = 768.  A 6-stage ring (120 KiB in flight) ran at the same 0.72 us per 32-k step as the 3-stage one:
 // not load latency but the VMEM issue slots inside the MFMA stream, which is what the loader waves remove.)
 //
+// (Tried and dropped, round 2: a stream-K cut of the K,K item list - equal k-step ranges, fp32 hand-over of the split
+// tiles through a workspace with device-coherent (sc1) stores / loads, item order by ownership so that the workgroups
+// still sweep the list together - to spread the epilogues over the main loops of other CUs: 129 vs 66 us at N = 3072.
+// The write-through hand-over of 256 x 147 KB costs 21 us, the coherent read-back 5 us, and the de-synchronised
+// epilogue itself was only ~13 % shorter: it is latency-structured (3 passes x staging + 2 barriers + row pass),
+// not purely HBM-bound.  Agent-scope fences instead of sc1 accesses were worse: each one writes back / drops the L2.)
+//
 // Epilogue, K,K: accumulators -> LDS (fp32, the ring slot that was read last, 64 rows per pass, 16-byte
 // chunks XOR-swizzled by row) -> all 8 waves apply bias / GELU / dropout / residual / gelu' on full rows
 // and store 16 B per lane.  The MFMA operands are swapped (D^T = B A^T) so that a lane holds 4
@@ -52,7 +59,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 #ifdef HERO_WS_TRACE
-// timeline probe (tools/lab/ws_trace.py): s_memtime stamps of the first four items of workgroup 0, per wave
+// timeline probe (tools/lab/trace_ws.py): s_memtime stamps of the first four items of workgroup 0, per wave
 __device__ unsigned long long g_ws_trace[4 * 16 * 8];
 #define WS_T(item_no, ev, wave, lane)                                                                   \
   do {                                                                                                  \
@@ -237,6 +244,11 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
   const bool do_csum = (EK & EK_GELU_BWD) && e.colsum != nullptr;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+  // A pass stages 64 rows.  With three passes over a 192-row tile the two 32-row blocks of a pass are taken from the
+  // two wave rows (block p of each), so that all four compute waves stage 12 fragments per pass instead of two waves
+  // staging 24 (the staging of a pass was 2100 cycles of a 5300-cycle pass, tools/lab/trace_ws.py).
+  constexpr bool SPLIT = (RPP == 64 && G::PASSES == TM);
+  auto tile_row = [](int p, int row) { return SPLIT ? (row >> 5) * (TM * 32) + p * 32 + (row & 31) : p * RPP + row; };
 
 #pragma unroll
   for (int p = 0; p < G::PASSES; ++p) {
@@ -247,7 +259,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int row = r0 + it * RPI;
-      const int gm = ic.m0 + p * RPP + row;
+      const int gm = ic.m0 + tile_row(p, row);
       ok[it] = col_ok && row < RPP && gm < g.M;
       off[it] = (unsigned)min(gm, g.M - 1) * (unsigned)g.ldc + (unsigned)gnc;
       if (EK & EK_RES) pre[it] = *reinterpret_cast<const uint4*>(R + off[it]);
@@ -257,7 +269,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
     if constexpr (COMPUTE) {
 #pragma unroll
       for (int b = 0; b < RPP / 32; ++b) {
-        const int blk = p * (RPP / 32) + b;          // 32-row block of the tile
+        const int blk = SPLIT ? b * TM + p : p * (RPP / 32) + b;   // 32-row block of the tile
         if (wm == blk / TM) {
           const int i = blk % TM;                     // compile-time after unrolling
 #pragma unroll
@@ -306,7 +318,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
           for (int k = 0; k < 8; ++k) v[k] *= gelu_grad<bf16_t>(pv[k]);
         }
         if (use_drop) {
-          const int gm = ic.m0 + p * RPP + row;
+          const int gm = ic.m0 + tile_row(p, row);
           const uint64_t grp = ((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2;
           const float4 m0 = drop.mask4(grp), m1 = drop.mask4(grp + 1);
           v[0] *= m0.x; v[1] *= m0.y; v[2] *= m0.z; v[3] *= m0.w;

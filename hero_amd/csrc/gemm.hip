@@ -457,6 +457,11 @@ struct GldsStage {
   }
 };
 
+template <typename CF> struct GldsRing {
+  static constexpr int NS = CF::BM * CF::BN <= 64 * 64 ? 4 : 2;
+  static constexpr int LDS = NS * CF::STAGE > CF::EPI_BYTES ? NS * CF::STAGE : CF::EPI_BYTES;
+};
+
 template <typename T, typename CF, int EK>
 __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_glds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -482,25 +487,45 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) 
   const T* pa = static_cast<const T*>(g.A) + (size_t)m0 * g.lda + tc.kbeg;
   const T* pb = static_cast<const T*>(g.B) + (size_t)n0 * g.ldb + tc.kbeg;
   const int nk = (tc.kend - tc.kbeg) / BK;
-  if (nk > 0) {
-    sa.issue(pa, smem);
-    sb.issue(pb, smem + CF::A_BYTES);
-  }
-  // An LDS-DMA is ordered for other waves' ds_reads only by the issuing wave's vmcnt + a barrier.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                   // tile 0 has landed
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * CF::STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * CF::STAGE;
-    if (kt + 1 < nk) {
-      pa += BK;
-      pb += BK;
-      sa.issue(pa, nxt);
-      sb.issue(pb, nxt + CF::A_BYTES);
+  // Ring of NSG stages, NSG - 1 of them in flight (counted vmcnt).  The 64 x 64 tiles serve the problems that are too
+  // small to fill the chip (the 1920-row Temporal Transformer / query shapes): one or two workgroups per CU and only
+  // 8 MFMAs per wave and step, so a step costs the load round trip divided by the stages in flight - 0.67 us with
+  // one stage ahead (48 steps at K = 3072 = 32 us).  Larger tiles keep two stages (64-80 KiB, two workgroups / CU).
+  constexpr int NSG = GldsRing<CF>::NS;
+  constexpr int PW = GldsStage<T, BM, NT>::PER_WAVE + GldsStage<T, BN, NT>::PER_WAVE;
+  static_assert((NSG - 1) * PW <= 60, "vmcnt range");
+  auto wait_stages = [](int later) {            // at most `later` whole stages may still be in flight
+    if (NSG > 3 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+    else if (NSG > 2 && later >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  const T* qa = pa;
+  const T* qb = pb;
+#pragma unroll
+  for (int d = 0; d < NSG - 1; ++d)
+    if (d < nk) {
+      sa.issue(qa, smem + d * CF::STAGE);
+      sb.issue(qb, smem + d * CF::STAGE + CF::A_BYTES);
+      qa += BK;
+      qb += BK;
     }
+  // An LDS-DMA is ordered for other waves' ds_reads only by the issuing wave's vmcnt + a barrier.
+  wait_stages(min(NSG - 2, nk - 1));
+  __syncthreads();                                   // tile 0 has landed
+  int cs = 0, fs = NSG - 1;                          // slot being read / slot to fill (the one read in the previous step)
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + cs * CF::STAGE;
+    if (kt + NSG - 1 < nk) {
+      sa.issue(qa, smem + fs * CF::STAGE);
+      sb.issue(qb, smem + fs * CF::STAGE + CF::A_BYTES);
+      qa += BK;
+      qb += BK;
+    }
+    cs = cs + 1 == NSG ? 0 : cs + 1;
+    fs = fs + 1 == NSG ? 0 : fs + 1;
     Mma<T, TM, TN>::tile(cur, cur + CF::A_BYTES, arow0, brow0, lane, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                 // next tile landed, everyone done with cur
+    wait_stages(min(NSG - 2, nk - 2 - kt));          // tile kt + 1 landed
+    __syncthreads();                                 // ... and everyone is done with cur
   }
   gemm_epilogue<T, CF, EK>(g, acc, smem, m0, n0, arow0, brow0, lane);
 }
@@ -858,7 +883,7 @@ template <typename T, typename CF, int EK>
 static int launch_glds_ek(GemmArgs g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, CF, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, CF, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, GldsRing<CF>::LDS);
     attr_set = true;
   }
   g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
@@ -875,7 +900,7 @@ static int launch_glds_ek(GemmArgs g, hipStream_t s) {
       ps = nullptr;
     }
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<T, CF, EK>), dim3(grid), dim3(CF::NT), CF::LDS, s, g);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, CF, EK>), dim3(grid), dim3(CF::NT), GldsRing<CF>::LDS, s, g);
   if (ps) {
     (void)hipEventRecord(e1, s);
     ps->ev.push_back(e0);

@@ -27,7 +27,6 @@ def main():
     else:
         dist.init_process_group(backend)
     import hero_amd
-    from hero_amd import functional as HF
     from hero_amd.step import TrainStep
     from hero_amd.synth import make_batch
     from hero_amd.utils.misc import set_dropout

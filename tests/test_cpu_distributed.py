@@ -5,7 +5,6 @@ collective (model/pretrain.py:427-447)."""
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -10,13 +10,12 @@ CPU oracle (oracle == reference: tests/test_oracle_golden.py):
     the middle must converge like the eager run.
 """
 import json
-import os
 
 import pytest
 import torch
 
 from oracle import hero_oracle as O
-from tests.util import GOLDEN, load_tiny, rel_err, to_dev
+from tests.util import rel_err, to_dev
 
 pytestmark = pytest.mark.gpu
 

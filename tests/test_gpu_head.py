@@ -1,7 +1,6 @@
 """VSM / VCMR head kernels (include/hero_hip.h "task head") against the PyTorch formulation of the
 same maths that hero_amd/model/pretrain.py keeps for the non-training configurations - forward
 values and every gradient, fp32 (tolerance: summation order only) and bf16 inputs."""
-import math
 import os
 
 import pytest

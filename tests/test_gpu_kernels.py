@@ -175,7 +175,6 @@ def test_wgrad_group_stream_k(HF, Lb, rows):
     """hero_wgrad_group: the four weight gradients of a BertLayer (QKV 2304x768, out 768x768, FFN1 3072x768, FFN2
     768x3072) over the same rows in ONE stream-K launch, accumulated into existing values; the reduction tail
     (rows % 64 != 0), a column-sliced dY, and the small-problem fallback (one hero_gemm per problem)."""
-    import ctypes as C
     dtype = torch.bfloat16
     shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
     dys = [rnd(rows, n, dtype=dtype, seed=10 + i) for i, (n, _) in enumerate(shapes)]

@@ -1,8 +1,6 @@
 """Shared helpers for the parity tests (fixtures -> hero_amd models / device batches)."""
-import json
 import os
 
-import numpy as np
 import torch
 
 from oracle import hero_oracle as O

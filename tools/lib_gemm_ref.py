@@ -4,7 +4,7 @@ next to hero_gemm / hero_wgrad_group on the same box.  Plain GEMMs only (no fuse
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hero_amd import functional as HF, _lib as L
+from hero_amd import functional as HF
 
 
 def timeit(fn, n=20, warm=5):

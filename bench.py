@@ -104,26 +104,34 @@ def build_pretraining_model(device, cfg_path):
     return model
 
 
-def cpu_baseline(model, cfg, sample_videos=8, reps=3):
+def cpu_baseline(model, cfg, sample_videos=16, reps=5, threads=16):
     """The CPU oracle (kind 'port': verified == reference in tests/test_oracle_golden.py) timed on
-    this box's host cores on a bounded sample of the same workload."""
+    this box's host cores on a bounded sample of the same workload.  16 threads: measured best on the GPU box
+    (tools/cpu_threads_probe.py on 256 logical CPUs: 8 -> 4.6, 16 -> 6.6, 32 -> 5.9, 64 -> 2.9, 128 (torch's default)
+    -> 1.3 videos/s; the oracle's small per-subtitle ops do not scale past one CCD)."""
     from hero_amd.synth import make_batch
     from oracle import hero_oracle as O
     P = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and not k.endswith("pad"))
          for k, v in model.state_dict().items()}
     batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1, videos=sample_videos)
     ocfg = O.cfg_from_json(cfg)
+    before = torch.get_num_threads()
+    threads = max(1, min(threads, os.cpu_count() or threads))
+    torch.set_num_threads(threads)
     times = []
-    for i in range(reps + 1):
-        for p in P.values():
-            p.grad = None
-        t0 = time.perf_counter()
-        losses = O.vsm_losses(batch, P, ocfg, p_drop=0.1)
-        sum(losses).backward()
-        times.append(time.perf_counter() - t0)
+    try:
+        for i in range(reps + 1):
+            for p in P.values():
+                p.grad = None
+            t0 = time.perf_counter()
+            losses = O.vsm_losses(batch, P, ocfg, p_drop=0.1)
+            sum(losses).backward()
+            times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(before)
     times = sorted(times[1:])
     med = times[len(times) // 2]
-    return {"value": sample_videos / med, "unit": "videos/s", "cores": torch.get_num_threads(),
+    return {"value": sample_videos / med, "unit": "videos/s", "cores": threads,
             "kind": "port",
             "sample": "%d-video slice of the D2 batch, fwd+loss+bwd fp32, dropout 0.1, 1 warm-up + %d timed, "
                       "median %.2f s" % (sample_videos, reps, med)}

@@ -260,6 +260,39 @@ def test_grad_arena_bf16_wire_format():
     assert all(spawn(_arena_bf16_wire))
 
 
+def _arena_forced_one_rank(rank, world):
+    """HERO_DP_FORCE_COLLECTIVES=1 with ONE rank (how the RCCL path is exercised on a 1-GPU box): the buckets go
+    through the process group although world_size == 1, and the gradients equal the unsynchronised ones."""
+    import os
+    from hero_amd import functional as HF
+    from hero_amd.utils import distributed as D
+    assert world == 1 and not D.collectives_active()
+    os.environ["HERO_DP_FORCE_COLLECTIVES"] = "1"
+    try:
+        assert D.collectives_active()
+        torch.manual_seed(0)
+        w1 = torch.nn.Parameter(torch.randn(40, 6))
+        w2 = torch.nn.Parameter(torch.randn(6, 6))
+        arena = D.GradArena([w1, w2], bucket_bytes=64, overlap=True, compress="bf16")
+        x = torch.randn(4, 40)
+        arena.set_sync(True)
+        ((x @ w1) @ w2).sum().backward()
+        launched = sum(arena._launched)
+        arena.finish()
+        a, b = w1.detach().clone().requires_grad_(), w2.detach().clone().requires_grad_()
+        ((x @ a) @ b).sum().backward()
+        ok = launched >= 1 and len(arena._wire) == len(arena.buckets)
+        ok = ok and torch.allclose(w1.grad, a.grad.to(torch.bfloat16).float()) and torch.allclose(w2.grad, b.grad.to(torch.bfloat16).float())
+    finally:
+        del os.environ["HERO_DP_FORCE_COLLECTIVES"]
+        HF.set_grad_sink(None)
+    return bool(ok)
+
+
+def test_forced_collectives_with_one_rank():
+    assert all(spawn(_arena_forced_one_rank, world=1))
+
+
 def _negatives(rank, world):
     from hero_amd.utils import distributed as D
     torch.manual_seed(rank)

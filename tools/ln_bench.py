@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""LayerNorm forward / backward micro-benchmark at the shapes of the HERO step (run on the GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hero_amd import functional as HF
+
+
+def timeit(fn, n=40, warm=3):
+    """kernel time: n calls captured in one hipGraph (no host gaps), replayed 5 times"""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(warm): fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(n): fn()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): g.replay()
+        e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (5 * n) * 1e3
+
+
+def main():
+    dt = torch.bfloat16
+    for rows in (12000, 1920):
+        cols = 768
+        x = torch.randn(rows, cols, device="cuda").to(dt); dy = torch.randn(rows, cols, device="cuda").to(dt)
+        g = torch.randn(cols, device="cuda"); b = torch.randn(cols, device="cuda")
+        drop = HF.RNG.make(0.1, True, x.device)
+        y, mean, rstd, _ = HF.k_ln_fwd(x, g, b, 1e-12, dt, rows, cols)
+        ref = torch.nn.functional.layer_norm(x.float(), (cols,), g, b, 1e-12)
+        err = (y.float() - ref).abs().max().item()
+        dg = torch.zeros(cols, device="cuda"); db = torch.zeros(cols, device="cuda"); dbi = torch.zeros(cols, device="cuda")
+        f = timeit(lambda: HF.k_ln_fwd(x, g, b, 1e-12, dt, rows, cols))
+        bw = timeit(lambda: HF.k_ln_bwd(x, dy, g, mean, rstd, drop_in=drop, dgamma=dg, dbeta=db, grad_beta=1.0, dbias_in=dbi))
+        bw0 = timeit(lambda: HF.k_ln_bwd(x, dy, g, mean, rstd, dgamma=dg, dbeta=db, grad_beta=1.0))
+        e = x.element_size()
+        print("rows %5d: fwd %6.1f us (%.2f TB/s, max err %.3g)   bwd+dropped copy %6.1f us (%.2f TB/s)   bwd %6.1f us (%.2f TB/s)"
+              % (rows, f, 2 * rows * cols * e / f / 1e6, err, bw, 4 * rows * cols * e / bw / 1e6, bw0, 3 * rows * cols * e / bw0 / 1e6))
+
+
+if __name__ == "__main__":
+    main()

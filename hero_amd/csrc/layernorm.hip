@@ -9,90 +9,71 @@
 
 namespace hero {
 
-#ifndef HERO_LN_RPW
-#define HERO_LN_RPW 1
-#endif
-// RPW rows per wave: their loads are issued together (more bytes in flight per wave, fewer waves to dispatch)
 template <typename TX, typename TY, int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(HeroLnFwd a) {
-  constexpr int RPW = HERO_LN_RPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * RPW;
-  if (row0 >= a.rows) return;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
   const int cols = a.cols;
-  float4 v[RPW][VPL];
-  float s[RPW];
+  const TX* x = a.x ? static_cast<const TX*>(a.x) + (size_t)row * cols : nullptr;
+  const float* t[3];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int row = min(row0 + r, a.rows - 1);
-    const TX* x = a.x ? static_cast<const TX*>(a.x) + (size_t)row * cols : nullptr;
-    const float* t[3];
+  for (int k = 0; k < 3; ++k)
+    t[k] = a.tab[k] ? a.tab[k] + (size_t)(a.idx[k] ? a.idx[k][row] : 0) * cols : nullptr;
+
+  float4 v[VPL];
+  float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      t[k] = a.tab[k] ? a.tab[k] + (size_t)(a.idx[k] ? a.idx[k][row] : 0) * cols : nullptr;
-    s[r] = 0.f;
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+      if (x) u = V4<TX>::ld(x + c);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < cols) {
-        if (x) u = V4<TX>::ld(x + c);
+      for (int k = 0; k < 3; ++k)
+        if (t[k]) {
+          const float4 w = *reinterpret_cast<const float4*>(t[k] + c);
+          u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+        }
+      s += (u.x + u.y) + (u.z + u.w);
+    }
+    v[i] = u;
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (t[k]) {
-            const float4 w = *reinterpret_cast<const float4*>(t[k] + c);
-            u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
-          }
-        s[r] += (u.x + u.y) + (u.z + u.w);
-      }
-      v[r][i] = u;
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
   }
-  float mean[RPW], rstd[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) mean[r] = wave_sum(s[r]) / (float)cols;
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < cols) {
-        const float dx = v[r][i].x - mean[r], dy = v[r][i].y - mean[r], dz = v[r][i].z - mean[r], dw = v[r][i].w - mean[r];
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-    }
-    rstd[r] = 1.0f / sqrtf(wave_sum(q) / (float)cols + a.eps);
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
   }
   DropCtx drop(a.dropout);
+  TY* y = static_cast<TY*>(a.y) + (size_t)row * cols;
+  TY* pre = a.pre ? static_cast<TY*>(a.pre) + (size_t)row * cols : nullptr;
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int row = row0 + r;
-    if (row >= a.rows) break;
-    if (lane == 0) {
-      if (a.mean) a.mean[row] = mean[r];
-      if (a.rstd) a.rstd[row] = rstd[r];
-    }
-    TY* y = static_cast<TY*>(a.y) + (size_t)row * cols;
-    TY* pre = a.pre ? static_cast<TY*>(a.pre) + (size_t)row * cols : nullptr;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < cols) {
-        if (pre) V4<TY>::st(pre + c, v[r][i]);
-        const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
-        const float4 b = *reinterpret_cast<const float4*>(a.beta + c);
-        float4 o;
-        o.x = (v[r][i].x - mean[r]) * rstd[r] * g.x + b.x;
-        o.y = (v[r][i].y - mean[r]) * rstd[r] * g.y + b.y;
-        o.z = (v[r][i].z - mean[r]) * rstd[r] * g.z + b.z;
-        o.w = (v[r][i].w - mean[r]) * rstd[r] * g.w + b.w;
-        if (drop.on()) {
-          const float4 m = drop.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
-          o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
-        }
-        V4<TY>::st(y + c, o);
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < cols) {
+      if (pre) V4<TY>::st(pre + c, v[i]);
+      const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(a.beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (drop.on()) {
+        const float4 m = drop.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
+        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
       }
+      V4<TY>::st(y + c, o);
     }
   }
 }
@@ -442,7 +423,7 @@ extern "C" int hero_layernorm_fwd(const HeroLnFwd* a, hero_stream_t stream) {
   HERO_REQUIRE(a->cols > 0 && a->cols % 4 == 0, "hero_layernorm_fwd: cols (%d) must be a positive multiple of 4", a->cols);
   if (a->rows <= 0) return HERO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((a->rows + 4 * HERO_LN_RPW - 1) / (4 * HERO_LN_RPW)), block(256);
+  const dim3 grid((a->rows + 3) / 4), block(256);
   const int xd = a->x ? a->x_dtype : a->y_dtype, yd = a->y_dtype;
 #define CALL(V)                                                                                                   \
   if (xd == HERO_F32 && yd == HERO_F32) hipLaunchKernelGGL((ln_fwd_kernel<float, float, V>), grid, block, 0, s, *a);        \

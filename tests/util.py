@@ -22,6 +22,18 @@ def load_tiny(device, cls=None, **kw):
     return model.to(device), P, O.cfg_from_json(cfgj)
 
 
+def elem_rel_err(a, b, mask=None):
+    """ELEMENT-WISE relative error, max over elements of |a-b| / (|b| + rms(b)) - stricter than `rel_err`, which
+    divides by the global maximum: every element must be right relative to its own size (floored at the tensor's rms
+    so that exact zeros do not make it meaningless)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if mask is not None:
+        m = mask.bool().cpu()
+        a, b = a[m], b[m]
+    rms = b.pow(2).mean().sqrt().clamp_min(1e-12)
+    return float(((a - b).abs() / (b.abs() + rms)).max())
+
+
 def to_dev(batch, device):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
 

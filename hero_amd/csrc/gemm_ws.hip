@@ -697,8 +697,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_barrier();                                       // B(-1)
   unsigned curo = 0;
   ldf(a0, b0, smem, 0);
-  for (int pos = start; pos < end;) {
+  int seg_no = 0;
+  for (int pos = start; pos < end; ++seg_no) {
     const Seg sg = seg_at<G>(g, pos, end);
+    WS_T(seg_no, 0, wave, lane);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -731,6 +733,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
     }
     pos += sg.nk;
+    WS_T(seg_no, 1, wave, lane);
+#ifdef HERO_WS_TRACE
+    if (blockIdx.x == 0 && lane == 0 && seg_no < 4) g_ws_trace[(seg_no * 16 + 3) * 8 + wave] = (unsigned long long)sg.nk;
+#endif
     const WsgProb& P = g.p[sg.prob];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -743,6 +749,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if (gm < P.M && gn < P.N) atomicAdd(P.C + (size_t)gm * P.ldc + gn, acc[i][j][r]);
         }
       }
+    WS_T(seg_no, 14, wave, lane);
   }
 }
 

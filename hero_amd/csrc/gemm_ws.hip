@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_barrier();                                       // B(-1)
   unsigned curo = 0;
   ldf(a0, b0, smem, 0);
-  int seg_no = 0;
+  [[maybe_unused]] int seg_no = 0;
   for (int pos = start; pos < end; ++seg_no) {
     const Seg sg = seg_at<G>(g, pos, end);
     WS_T(seg_no, 0, wave, lane);

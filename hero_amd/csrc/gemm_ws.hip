@@ -50,6 +50,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 constexpr int NS = 3;                 // ring stages
 constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-sum fold
@@ -69,16 +70,6 @@ __device__ unsigned long long g_ws_trace[4 * 16 * 8];
 #else
 #define WS_T(item_no, ev, wave, lane) do { } while (0)
 #endif
-
-// output stores of the K,K epilogue (A/B hook: -DHERO_WS_NT_STORE streams them past the L2)
-__device__ __forceinline__ void st_out(uint4* p, uint4 v) {
-#ifdef HERO_WS_NT_STORE
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
-#else
-  *p = v;
-#endif
-}
 
 struct WsArgs {
   const void* A;
@@ -232,6 +223,10 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
   bf16_t* Cb = static_cast<bf16_t*>(g.C);
   const bf16_t* R = (EK & EK_RES) ? static_cast<const bf16_t*>(e.residual) : nullptr;
   bf16_t* X = static_cast<bf16_t*>(e.aux);
+  // tile-relative store descriptors (offsets inside a tile stay far below 2^31 bytes whatever the size of C)
+  const size_t torg = (size_t)ic.m0 * g.ldc + ic.n0;
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(Cb + torg, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((EK & EK_GELU) ? X + torg : Cb + torg, 0, 0x7fffffff, 0x00020000);
   DropCtx drop(e.dropout);
   const bool use_drop = (EK & EK_DROP) && drop.on();
   float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -287,10 +282,15 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
     WS_T(trace_item, 3 + 4 * p, wave, lane);
     __builtin_amdgcn_s_barrier();                    // E1: the pass is staged
     WS_T(trace_item, 4 + 4 * p, wave, lane);
+    // All iterations are computed first (branch-free: inactive threads and rows past the pass read a clamped row and
+    // store nothing), THEN the stores are issued back to back.  With a store inside each iteration the compiler put
+    // an s_waitcnt vmcnt(0) in front of the next iteration's arithmetic (its registers were the store's data), i.e.
+    // every iteration waited for the previous store's round trip to HBM: 4 serialised round trips per pass.
+    uint4 outv[ITERS], auxv[(EK & EK_GELU) ? ITERS : 1];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int row = r0 + it * RPI;
-      if (active && row < RPP) {
+      const int row = min(r0 + it * RPI, RPP - 1);
+      {
         const int x = row & 7;
         const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(st + row * G::ROWB + (((2 * c8) ^ x) << 4));
         const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(st + row * G::ROWB + (((2 * c8 + 1) ^ x) << 4));
@@ -300,7 +300,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
         if (EK & EK_GELU) {
           uint4 u;
           u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
-          if (ok[it]) st_out(reinterpret_cast<uint4*>(X + off[it]), u);
+          auxv[(EK & EK_GELU) ? it : 0] = u;
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
         }
@@ -334,8 +334,20 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
         }
         uint4 o;
         o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
-        if (ok[it]) st_out(reinterpret_cast<uint4*>(Cb + off[it]), o);
+        outv[it] = o;
       }
+    }
+    // Branch-free stores: a masked-off lane gets an offset past the descriptor's range and the hardware drops it.
+    // (Behind `if (ok)` every store sat in its own basic block, and each block re-waited vmcnt(0) for the bias /
+    // residual loads of the tile start - which by then also meant the previous block's store.)
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const unsigned vo = ok[it] ? (unsigned)(tile_row(p, r0 + it * RPI) * g.ldc + c8 * 8) * 2u : 0xffffffffu;
+      if (EK & EK_GELU) {
+        const uint4 u = auxv[(EK & EK_GELU) ? it : 0];
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{u.x, u.y, u.z, u.w}, rsx, vo, 0, 0);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{outv[it].x, outv[it].y, outv[it].z, outv[it].w}, rsc, vo, 0, 0);
     }
     wait_lds();
     WS_T(trace_item, 5 + 4 * p, wave, lane);

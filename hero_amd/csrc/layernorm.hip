@@ -78,6 +78,66 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(HeroLnFwd a) {
   }
 }
 
+// Straight-line form for the common case (x given, no embedding tables, cols == VPL * 256): no per-chunk branches, so all
+// loads of a row - and gamma / beta - are in flight together.  In the general kernel above every chunk sits in its
+// own basic block (`if (c < cols)`, `if (x)`, `if (t[k])`) and the compiler waits vmcnt(0) right after each load:
+// three serial round trips per 768-wide row.
+template <typename TX, typename TY, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_full_kernel(HeroLnFwd a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  constexpr int cols = VPL * 256;
+  const TX* x = static_cast<const TX*>(a.x) + (size_t)row * cols;
+  float4 v[VPL], g[VPL], b[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) v[i] = V4<TX>::ld(x + (lane + 64 * i) * 4);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+    b[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+  DropCtx drop(a.dropout);
+  TY* y = static_cast<TY*>(a.y) + (size_t)row * cols;
+  TY* pre = a.pre ? static_cast<TY*>(a.pre) + (size_t)row * cols : nullptr;
+  float4 o[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    o[i].x = (v[i].x - mean) * rstd * g[i].x + b[i].x;
+    o[i].y = (v[i].y - mean) * rstd * g[i].y + b[i].y;
+    o[i].z = (v[i].z - mean) * rstd * g[i].z + b[i].z;
+    o[i].w = (v[i].w - mean) * rstd * g[i].w + b[i].w;
+  }
+  if (drop.on()) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float4 m = drop.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)((lane + 64 * i) * 4)) >> 2);
+      o[i].x *= m.x; o[i].y *= m.y; o[i].z *= m.z; o[i].w *= m.w;
+    }
+  }
+  if (pre) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) V4<TY>::st(pre + (lane + 64 * i) * 4, v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) V4<TY>::st(y + (lane + 64 * i) * 4, o[i]);
+}
+
 template <typename TX, typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(HeroLnBwd a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -213,6 +273,102 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(HeroLnBwd a, float* p
   }
   __syncthreads();
   const int n4 = 3 * (cols >> 2);
+  for (int q = threadIdx.x; q < n4; q += 256) {
+    const int k = q / (cols >> 2), c = (q - k * (cols >> 2)) * 4;
+    float4 v = *reinterpret_cast<const float4*>(red + (size_t)k * cols + c);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 u = *reinterpret_cast<const float4*>(red + ((size_t)(w * 3 + k)) * cols + c);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 3 + k) * cols + c) = v;
+  }
+}
+
+// Straight-line form of the fused backward (cols == VPL * 256): gamma lives in registers for the whole kernel and
+// all loads of a row are issued before anything is used (the general kernel waits vmcnt(0) after each chunk's load
+// because every chunk is a basic block of its own).
+template <typename TX, typename T, int VPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void ln_bwd_fused_full_kernel(HeroLnBwd a, float* partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];       // [4 waves][3][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int cols = VPL * 256;
+  DropCtx dout(a.dropout_out), din(a.dropout_in);
+  float4 ag[VPL], ab[VPL], ai[VPL], gm[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ag[i] = ab[i] = ai[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+  }
+  const float inv = 1.f / (float)cols;
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    const TX* x = static_cast<const TX*>(a.x) + (size_t)row * cols;
+    const T* dy = static_cast<const T*>(a.dy) + (size_t)row * cols;
+    float4 xv[VPL], d[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      xv[i] = V4<TX>::ld(x + (lane + 64 * i) * 4);
+      d[i] = V4<T>::ld(dy + (lane + 64 * i) * 4);
+    }
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    if (dout.on()) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const float4 m = dout.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)((lane + 64 * i) * 4)) >> 2);
+        d[i].x *= m.x; d[i].y *= m.y; d[i].z *= m.z; d[i].w *= m.w;
+      }
+    }
+    float4 xh[VPL], g[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      xh[i] = make_float4((xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd);
+      g[i] = make_float4(d[i].x * gm[i].x, d[i].y * gm[i].y, d[i].z * gm[i].z, d[i].w * gm[i].w);
+      ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+      ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+    }
+    s1 = wave_sum(s1) * inv;
+    s2 = wave_sum(s2) * inv;
+    T* dx = a.dx ? static_cast<T*>(a.dx) + (size_t)row * cols : nullptr;
+    T* dxd = a.dx_dropped ? static_cast<T*>(a.dx_dropped) + (size_t)row * cols : nullptr;
+    float4 o[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      o[i].x = rstd * (g[i].x - s1 - xh[i].x * s2);
+      o[i].y = rstd * (g[i].y - s1 - xh[i].y * s2);
+      o[i].z = rstd * (g[i].z - s1 - xh[i].z * s2);
+      o[i].w = rstd * (g[i].w - s1 - xh[i].w * s2);
+    }
+    if (dx) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) V4<T>::st(dx + (lane + 64 * i) * 4, o[i]);
+    }
+    if (din.on()) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const float4 m = din.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)((lane + 64 * i) * 4)) >> 2);
+        o[i].x *= m.x; o[i].y *= m.y; o[i].z *= m.z; o[i].w *= m.w;
+      }
+    }
+    if (dxd) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) V4<T>::st(dxd + (lane + 64 * i) * 4, o[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { ai[i].x += o[i].x; ai[i].y += o[i].y; ai[i].z += o[i].z; ai[i].w += o[i].w; }
+  }
+  // ---- workgroup reduction of the three column partials (as in ln_bwd_fused_kernel)
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    *reinterpret_cast<float4*>(red + ((size_t)(wave * 3 + 0)) * cols + c) = ag[i];
+    *reinterpret_cast<float4*>(red + ((size_t)(wave * 3 + 1)) * cols + c) = ab[i];
+    *reinterpret_cast<float4*>(red + ((size_t)(wave * 3 + 2)) * cols + c) = ai[i];
+  }
+  __syncthreads();
+  constexpr int n4 = 3 * (cols >> 2);
   for (int q = threadIdx.x; q < n4; q += 256) {
     const int k = q / (cols >> 2), c = (q - k * (cols >> 2)) * 4;
     float4 v = *reinterpret_cast<const float4*>(red + (size_t)k * cols + c);
@@ -425,6 +581,17 @@ extern "C" int hero_layernorm_fwd(const HeroLnFwd* a, hero_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((a->rows + 3) / 4), block(256);
   const int xd = a->x ? a->x_dtype : a->y_dtype, yd = a->y_dtype;
+  if (a->x && !a->tab[0] && !a->tab[1] && !a->tab[2] && a->cols % 256 == 0 && a->cols <= 1024) {   // straight-line kernel
+#define CALLF(V)                                                                                                           \
+  if (xd == HERO_F32 && yd == HERO_F32) hipLaunchKernelGGL((ln_fwd_full_kernel<float, float, V>), grid, block, 0, s, *a);        \
+  else if (xd == HERO_F32 && yd == HERO_BF16) hipLaunchKernelGGL((ln_fwd_full_kernel<float, bf16_t, V>), grid, block, 0, s, *a); \
+  else if (xd == HERO_BF16 && yd == HERO_BF16) hipLaunchKernelGGL((ln_fwd_full_kernel<bf16_t, bf16_t, V>), grid, block, 0, s, *a); \
+  else { set_error("hero_layernorm_fwd: unsupported dtypes x=%d y=%d", xd, yd); return HERO_ERR_UNSUPPORTED; }
+    const int v = a->cols / 256;
+    if (v == 1) { CALLF(1); } else if (v == 2) { CALLF(2); } else if (v == 3) { CALLF(3); } else { CALLF(4); }
+#undef CALLF
+    return check_launch("hero_layernorm_fwd(full)");
+  }
 #define CALL(V)                                                                                                   \
   if (xd == HERO_F32 && yd == HERO_F32) hipLaunchKernelGGL((ln_fwd_kernel<float, float, V>), grid, block, 0, s, *a);        \
   else if (xd == HERO_F32 && yd == HERO_BF16) hipLaunchKernelGGL((ln_fwd_kernel<float, bf16_t, V>), grid, block, 0, s, *a); \
@@ -465,7 +632,15 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
   else if (xd == HERO_BF16 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_fused_kernel<bf16_t, bf16_t, V>), grid, block, lds, s, *a, partial); \
   else { set_error("hero_layernorm_bwd: unsupported dtypes x=%d dy=%d", xd, d); return HERO_ERR_UNSUPPORTED; }
     const int need = (a->cols + 255) / 256;
-    if (need <= 1) { CALLF(1); } else if (need <= 2) { CALLF(2); } else if (need <= 3) { CALLF(3); } else { CALLF(4); }
+    if (a->cols % 256 == 0) {                          // straight-line kernel
+#define CALLS(V)                                                                                                                   \
+  if (xd == HERO_F32 && d == HERO_F32) hipLaunchKernelGGL((ln_bwd_fused_full_kernel<float, float, V>), grid, block, lds, s, *a, partial);          \
+  else if (xd == HERO_F32 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_fused_full_kernel<float, bf16_t, V>), grid, block, lds, s, *a, partial);   \
+  else if (xd == HERO_BF16 && d == HERO_BF16) hipLaunchKernelGGL((ln_bwd_fused_full_kernel<bf16_t, bf16_t, V>), grid, block, lds, s, *a, partial); \
+  else { set_error("hero_layernorm_bwd: unsupported dtypes x=%d dy=%d", xd, d); return HERO_ERR_UNSUPPORTED; }
+      if (need <= 1) { CALLS(1); } else if (need <= 2) { CALLS(2); } else if (need <= 3) { CALLS(3); } else { CALLS(4); }
+#undef CALLS
+    } else if (need <= 1) { CALLF(1); } else if (need <= 2) { CALLF(2); } else if (need <= 3) { CALLF(3); } else { CALLF(4); }
 #undef CALLF
     int rc = check_launch("hero_layernorm_bwd(fused)");
     if (rc) return rc;

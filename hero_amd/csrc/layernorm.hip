@@ -451,7 +451,40 @@ __global__ __launch_bounds__(256) void colred_kernel(ColRed a) {
     DropCtx drop(a.dropout);
     const TX* x = static_cast<const TX*>(a.x);
     const T* dy = static_cast<const T*>(a.dy);
-    for (int r = r0 + ty; r < r1; r += 4) {
+    int r = r0 + ty;
+    // four rows per trip, their loads issued together (one load per trip left a single 8-byte request in flight per
+    // wave: 12 serial round trips per chunk)
+    for (; r + 12 < r1; r += 16) {
+      float4 d[4], xv[4];
+      float mu[4], rs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = V4<T>::ld(dy + (size_t)(r + 4 * u) * a.ld + c);
+      if (x) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = V4<TX>::ld(x + (size_t)(r + 4 * u) * a.cols + c);
+          mu[u] = a.mean[r + 4 * u];
+          rs[u] = a.rstd[r + 4 * u];
+        }
+      }
+      if (drop.on()) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 m = drop.mask4(((uint64_t)(r + 4 * u) * (uint64_t)a.cols + (uint64_t)c) >> 2);
+          d[u].x *= m.x; d[u].y *= m.y; d[u].z *= m.z; d[u].w *= m.w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { sb.x += d[u].x; sb.y += d[u].y; sb.z += d[u].z; sb.w += d[u].w; }
+      if (x) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sg.x += d[u].x * (xv[u].x - mu[u]) * rs[u]; sg.y += d[u].y * (xv[u].y - mu[u]) * rs[u];
+          sg.z += d[u].z * (xv[u].z - mu[u]) * rs[u]; sg.w += d[u].w * (xv[u].w - mu[u]) * rs[u];
+        }
+      }
+    }
+    for (; r < r1; r += 4) {
       float4 d = V4<T>::ld(dy + (size_t)r * a.ld + c);
       if (drop.on()) {
         const float4 m = drop.mask4(((uint64_t)r * (uint64_t)a.cols + (uint64_t)c) >> 2);

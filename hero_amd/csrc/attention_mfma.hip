@@ -149,11 +149,20 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
         float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
         if (drop.on()) m = drop.mask4((drow + j0) >> 2);
         const float mm[4] = {m.x, m.y, m.z, m.w};
+        float pr4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pr = p[jt][4 * q + e] * inv;
-          if (prow && i < L && j0 + e < L) prow[j0 + e] = pr;
-          p[jt][4 * q + e] = pr * mm[e];
+          pr4[e] = p[jt][4 * q + e] * inv;
+          p[jt][4 * q + e] = pr4[e] * mm[e];
+        }
+        if (prow && i < L) {
+          if ((Lm & 3) == 0 && j0 + 3 < L) {
+            *reinterpret_cast<float4*>(prow + j0) = make_float4(pr4[0], pr4[1], pr4[2], pr4[3]);   // one 16-byte store per run of 4 columns
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (j0 + e < L) prow[j0 + e] = pr4[e];
+          }
         }
       }
 #pragma unroll
@@ -242,14 +251,32 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
     const float* prow = a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm;
     const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
     float pr[NB][16], ds[NB][16];
+    // The saved probabilities of this lane's 16 accumulator slots are 4 runs of 4 consecutive columns: four 16-byte
+    // loads when the row stride allows it, used UNCONDITIONALLY (masked by a multiplication).  Written as
+    // `(i < L && j < L) ? prow[j] : 0` the compiler sank each of the 16 scalar loads into its own conditional block,
+    // each followed by s_waitcnt vmcnt(0): 16 serial round trips per 32-row block.
+    const float rowok = i < L ? 1.f : 0.f;
+    if ((Lm & 3) == 0) {
 #pragma unroll
-    for (int jt = 0; jt < NB; ++jt)
+      for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = 32 * jt + acc_row(r, half);
-        const float v = prow[min(j, L - 1)];
-        pr[jt][r] = (i < L && j < L) ? v : 0.f;
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int j0 = 32 * jt + 8 * q + 4 * half;
+          const float4 v = *reinterpret_cast<const float4*>(prow + min(j0, Lm - 4));
+          pr[jt][4 * q + 0] = v.x * (j0 + 0 < L ? rowok : 0.f);
+          pr[jt][4 * q + 1] = v.y * (j0 + 1 < L ? rowok : 0.f);
+          pr[jt][4 * q + 2] = v.z * (j0 + 2 < L ? rowok : 0.f);
+          pr[jt][4 * q + 3] = v.w * (j0 + 3 < L ? rowok : 0.f);
+        }
+    } else {
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * jt + acc_row(r, half);
+          pr[jt][r] = prow[min(j, L - 1)] * (j < L ? rowok : 0.f);
+        }
+    }
     float delta = 0.f;
 #pragma unroll
     for (int jt = 0; jt < NB; ++jt)

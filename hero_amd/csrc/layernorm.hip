@@ -9,45 +9,55 @@
 
 namespace hero {
 
+// General forward (any cols % 4 == 0, optional x, up to three gathered table rows).  Written in PHASES so that the
+// loads of a phase are in flight together: per-chunk branches (`if (c < cols)`, `if (x)`, `if (t[k])`) make every
+// chunk a basic block and the compiler waits vmcnt(0) right after each load (68 serial round trips for a 4352-wide
+// row).  A chunk past the row reads a clamped address and is multiplied by 0.
 template <typename TX, typename TY, int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(HeroLnFwd a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.rows) return;
   const int cols = a.cols;
-  const TX* x = a.x ? static_cast<const TX*>(a.x) + (size_t)row * cols : nullptr;
-  const float* t[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    t[k] = a.tab[k] ? a.tab[k] + (size_t)(a.idx[k] ? a.idx[k][row] : 0) * cols : nullptr;
-
-  float4 v[VPL];
-  float s = 0.f;
+  int cc[VPL];
+  float okf[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = (lane + 64 * i) * 4;
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < cols) {
-      if (x) u = V4<TX>::ld(x + c);
+    cc[i] = min(c, cols - 4);
+    okf[i] = c < cols ? 1.f : 0.f;
+  }
+  float4 v[VPL];
+  if (a.x) {                                          // uniform
+    const TX* x = static_cast<const TX*>(a.x) + (size_t)row * cols;
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (t[k]) {
-          const float4 w = *reinterpret_cast<const float4*>(t[k] + c);
-          u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
-        }
-      s += (u.x + u.y) + (u.z + u.w);
+    for (int i = 0; i < VPL; ++i) v[i] = V4<TX>::ld(x + cc[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (a.tab[k]) {                                   // uniform
+      const float* t = a.tab[k] + (size_t)(a.idx[k] ? a.idx[k][row] : 0) * cols;
+      float4 w[VPL];
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) w[i] = *reinterpret_cast<const float4*>(t + cc[i]);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) { v[i].x += w[i].x; v[i].y += w[i].y; v[i].z += w[i].z; v[i].w += w[i].w; }
     }
-    v[i] = u;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i].x *= okf[i]; v[i].y *= okf[i]; v[i].z *= okf[i]; v[i].w *= okf[i];
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(s) / (float)cols;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < cols) {
-      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
+    const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+    q += ((dx * dx + dy * dy) + (dz * dz + dw * dw)) * okf[i];
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + a.eps);
   if (lane == 0) {
@@ -57,24 +67,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(HeroLnFwd a) {
   DropCtx drop(a.dropout);
   TY* y = static_cast<TY*>(a.y) + (size_t)row * cols;
   TY* pre = a.pre ? static_cast<TY*>(a.pre) + (size_t)row * cols : nullptr;
+  constexpr int GRP = 4;                              // gamma / beta of GRP chunks are fetched together, then GRP stores
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < cols) {
-      if (pre) V4<TY>::st(pre + c, v[i]);
-      const float4 g = *reinterpret_cast<const float4*>(a.gamma + c);
-      const float4 b = *reinterpret_cast<const float4*>(a.beta + c);
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * g.x + b.x;
-      o.y = (v[i].y - mean) * rstd * g.y + b.y;
-      o.z = (v[i].z - mean) * rstd * g.z + b.z;
-      o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      if (drop.on()) {
-        const float4 m = drop.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)c) >> 2);
-        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+  for (int i0 = 0; i0 < VPL; i0 += GRP) {
+    float4 g[GRP], b[GRP];
+#pragma unroll
+    for (int u = 0; u < GRP; ++u)
+      if (i0 + u < VPL) {
+        g[u] = *reinterpret_cast<const float4*>(a.gamma + cc[i0 + u]);
+        b[u] = *reinterpret_cast<const float4*>(a.beta + cc[i0 + u]);
       }
-      V4<TY>::st(y + c, o);
-    }
+#pragma unroll
+    for (int u = 0; u < GRP; ++u)
+      if (i0 + u < VPL) {
+        const int i = i0 + u;
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g[u].x + b[u].x;
+        o.y = (v[i].y - mean) * rstd * g[u].y + b[u].y;
+        o.z = (v[i].z - mean) * rstd * g[u].z + b[u].z;
+        o.w = (v[i].w - mean) * rstd * g[u].w + b[u].w;
+        if (drop.on()) {
+          const float4 m = drop.mask4(((uint64_t)row * (uint64_t)cols + (uint64_t)cc[i]) >> 2);
+          o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+        }
+        if (okf[i] != 0.f) {
+          if (pre) V4<TY>::st(pre + cc[i], v[i]);
+          V4<TY>::st(y + cc[i], o);
+        }
+      }
   }
 }
 

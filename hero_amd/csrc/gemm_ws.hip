@@ -58,9 +58,6 @@ constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-
 #define HERO_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// the same wait as a builtin (vmcnt 63, expcnt 7, lgkmcnt 0 in the gfx9 encoding), which the compiler's wait-count pass
-// understands: after it no LDS read is pending in its model either
-__device__ __forceinline__ void wait_lds_tracked() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
 #ifdef HERO_WS_TRACE
 // timeline probe (tools/lab/trace_ws.py): s_memtime stamps of the first four items of workgroup 0, per wave
@@ -480,6 +477,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_setprio(2);
   __builtin_amdgcn_s_barrier();                                       // B(-1)
   unsigned curo = 0;
+  if (wg < g.nwork) ldf(a0, b0, smem, 0);
   int item_no = 0;
   for (int cit = wg; cit < g.nwork; cit += nwg, ++item_no) {
     const Item ic = item_coord<G>(g, cit);
@@ -490,27 +488,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // The loop body STARTS right after the step barrier (where every LDS read has been waited for) and ends with the
-    // next one, so the wait-count pass sees the same empty state on both ways into the loop header; and it has no
-    // branch.  With the header in front of the first fragment reads, and a conditional read after the barrier, the
-    // compiler drained ALL outstanding reads (lgkmcnt(0)) in front of two of the four MFMA groups of every step -
-    // a full LDS latency of MFMA idle, twice per step.  The last quarter of a step is issued at the top of the next
-    // pass (zero fragments on the first one), the final one after the loop.
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a1[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b1[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    const bool more_items = cit + nwg < g.nwork;
     unsigned last = curo;
-    wait_lds_tracked();                                               // the same (empty) LDS state on the way in as on the back edge
     for (int t = 0; t < ic.nk; ++t) {
       const char* cur = smem + curo;
       last = curo;
       curo += G::STAGE;
       if (curo == NS * G::STAGE) curo = 0;
-      ldf(a0, b0, cur, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a1, b1);                                                    // last quarter of the previous step
-      __builtin_amdgcn_sched_barrier(0);
+      const char* nxt = smem + curo;
       ldf(a1, b1, cur, 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
@@ -523,17 +508,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      wait_lds_tracked();
+      wait_lds();
       __builtin_amdgcn_s_barrier();                                   // B(u): done reading `cur`, stage u+1 landed
       __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ic.nk || (TR && more_items)) ldf(a0, b0, nxt, 0);   // K,K: the next item's first slice is read after the epilogue
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    mma(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
     if constexpr (!TR) {
       __builtin_amdgcn_s_setprio(0);
       WS_T(item_no, 1, wave, lane);
       epilogue_rows<G, EK, true>(g, ic, smem, last, acc, wave, lane, item_no);
       __builtin_amdgcn_s_setprio(2);
+      if (more_items) ldf(a0, b0, smem + curo, 0);
     } else {
       // fp32 atomics from the accumulator layout: 32 consecutive columns per half-wave, two rows per instruction
       float* C = static_cast<float*>(g.C);
@@ -720,6 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_setprio(2);
   __builtin_amdgcn_s_barrier();                                       // B(-1)
   unsigned curo = 0;
+  ldf(a0, b0, smem, 0);
   [[maybe_unused]] int seg_no = 0;
   for (int pos = start; pos < end; ++seg_no) {
     const Seg sg = seg_at<G>(g, pos, end);
@@ -730,20 +719,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // loop body from step barrier to step barrier, branch-free (see gemm_ws_kernel)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a1[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b1[j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    wait_lds_tracked();
     for (int t = 0; t < sg.nk; ++t) {
       const char* cur = smem + curo;
       curo += G::STAGE;
       if (curo == NS * G::STAGE) curo = 0;
-      ldf(a0, b0, cur, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a1, b1);                                                    // last quarter of the previous step
-      __builtin_amdgcn_sched_barrier(0);
+      const char* nxt = smem + curo;
       ldf(a1, b1, cur, 1);
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
@@ -756,12 +736,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      wait_lds_tracked();
+      wait_lds();
       __builtin_amdgcn_s_barrier();                                   // B(u)
       __builtin_amdgcn_sched_barrier(0);
+      if (pos + t + 1 < end) ldf(a0, b0, nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    mma(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
     pos += sg.nk;
     WS_T(seg_no, 1, wave, lane);
 #ifdef HERO_WS_TRACE

@@ -416,11 +416,22 @@ __global__ __launch_bounds__(256) void colred_final3_kernel(const float* partial
   const int per = (nblocks + gridDim.z - 1) / gridDim.z;
   const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < cols)
-    for (int b = b0 + kl; b < b1; b += 16) {
+  if (c < cols) {
+    int b = b0 + kl;
+    // four partials per trip, loads issued together (one per trip = one 16-byte request in flight per thread: the
+    // 8 trips of the 1024-block fold were 8 serial round trips, most of the kernel's 5 us)
+    for (; b + 48 < b1; b += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(partial + ((size_t)(b + 16 * u) * 3 + k) * cols + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; b < b1; b += 16) {
       const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)b * 3 + k) * cols + c);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
   red[kl][cg] = s;
   __syncthreads();
   if (kl == 0 && c < cols) {
@@ -551,7 +562,21 @@ __global__ __launch_bounds__(256) void colred_final_kernel(const float* pg, cons
   const int k0 = blockIdx.z * per, k1 = min(nchunks, k0 + per);
   float sg = 0.f, sb = 0.f;
   if (c < cols) {
-    for (int k = k0 + kl; k < k1; k += 16) {
+    int k = k0 + kl;
+    for (; k + 48 < k1; k += 64) {                     // four chunks per trip, loads issued together
+      float g4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (og) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g4[u] = pg[(size_t)(k + 16 * u) * cols + c];
+      }
+      if (ob) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b4[u] = pb[(size_t)(k + 16 * u) * cols + c];
+      }
+      sg += (g4[0] + g4[1]) + (g4[2] + g4[3]);
+      sb += (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    }
+    for (; k < k1; k += 16) {
       if (og) sg += pg[(size_t)k * cols + c];
       if (ob) sb += pb[(size_t)k * cols + c];
     }

@@ -24,7 +24,7 @@ EXPORTS = [
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
     "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
     "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
-    "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map",
+    "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats",
 ]
 
 
@@ -193,6 +193,7 @@ def lib():
                        ("hero_rank_loss", RankLoss), ("hero_st_ed_fwd", StEd), ("hero_st_ed_bwd", StEd)):
             getattr(L, fn).argtypes = [C.POINTER(st), C.c_void_p]
         L.hero_collate_subs.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
+        L.hero_collate_gather_feats.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
         L.hero_collate_clip_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hero_collate_frame_map.argtypes = [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]
         L.hero_cross_entropy_fwd.argtypes = [C.POINTER(CrossEntropy), C.c_void_p]

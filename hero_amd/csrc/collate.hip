@@ -9,7 +9,9 @@
 //   sub_frm_off[T + 1], sub_frm[...]   the frame indices (inside its video) of each subtitle
 //   vid_sub_off[B + 1], vid_nfrm[B]    first subtitle row / frame count of each video
 // Outputs, identical bit for bit to hero_amd/synth.py + hero_amd.model.model.build_frame_map:
-//   f_gather_index, f_attn_masks [T, max_vl + max_sl] int64, c_attn_masks [B, NF] int64,
+//   f_gather_index, f_attn_masks [T, out_size] int64 (out_size = max over rows of frame slots + tokens: the width
+//   the reference's pad_sequence gives f_attn_masks, data/data.py:433-436 - NOT max_vl + max_sl), c_attn_masks [B, NF] int64,
+//   f_v_feats [T, max_vl, D] gathered from c_v_feats [B, NF, D] (data/data.py:374-379: index_select per subtitle),
 //   frame map CSR: counts -> (exclusive scan by the caller) -> entries [nnz], inverse [T * Lf] int32
 #include "common.h"
 
@@ -19,8 +21,7 @@ namespace {
 // data/data.py:504-512 (get_gather_index) and :380-382 (a subtitle without frames keeps one zero frame slot
 // whose mask bit is 0); one thread per (row, position)
 __global__ void collate_subs_kernel(const int32_t* __restrict__ nfrm, const int32_t* __restrict__ ntok, int64_t* __restrict__ gidx,
-                                    int64_t* __restrict__ mask, int T, int max_vl, int max_sl) {
-  const int Lf = max_vl + max_sl;
+                                    int64_t* __restrict__ mask, int T, int max_vl, int Lf) {
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < (size_t)T * Lf; q += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(q / Lf), p = (int)(q - (size_t)r * Lf);
     const int nf = nfrm[r], nt = ntok[r], eff = nf > 0 ? nf : 1;
@@ -31,6 +32,38 @@ __global__ void collate_subs_kernel(const int32_t* __restrict__ nfrm, const int3
 
 __global__ void collate_clip_mask_kernel(const int32_t* __restrict__ vid_nfrm, int64_t* __restrict__ mask, int B, int NF) {
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < B * NF; q += gridDim.x * blockDim.x) mask[q] = (q % NF) < vid_nfrm[q / NF] ? 1 : 0;
+}
+
+// f_v_feats[r, k, :] = c_v_feats[video(r), k-th frame of subtitle r that lies inside its video, :], zero rows after them - the
+// per-subtitle copies of the frame features (data/data.py:371-379: frames outside the clipped video are dropped, then
+// index_select) made on the device, so that the host hands over c_v_feats only.  One workgroup per (row, slot),
+// 16-byte accesses.  `row_vid[r]` = the video of subtitle row r.
+__global__ void gather_feats_kernel(const float4* __restrict__ c_feats, float4* __restrict__ f_feats, const int32_t* __restrict__ row_vid,
+                                    const int32_t* __restrict__ vid_nfrm, const int32_t* __restrict__ frm_off, const int32_t* __restrict__ frm,
+                                    int max_vl, int NF, int D4) {
+  const int r = blockIdx.x / max_vl, k = blockIdx.x - r * max_vl;
+  float4* dst = f_feats + (size_t)blockIdx.x * D4;
+  const int nfv = vid_nfrm[row_vid[r]];
+  int f = -1, seen = 0;
+  for (int j = frm_off[r]; j < frm_off[r + 1]; ++j) {          // wave-uniform walk of a short list
+    const int c = frm[j];
+    if (c >= 0 && c < nfv) {
+      if (seen == k) { f = c; break; }
+      ++seen;
+    }
+  }
+  if (f < 0 || f >= NF) {
+    for (int c = threadIdx.x; c < D4; c += blockDim.x) dst[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float4* src = c_feats + ((size_t)row_vid[r] * NF + f) * D4;
+  for (int c = threadIdx.x; c < D4; c += blockDim.x) dst[c] = src[c];
+}
+
+// row_vid[r] = video of subtitle row r (vid_sub_off is the exclusive scan of num_subs)
+__global__ void row_video_kernel(const int32_t* __restrict__ vid_sub_off, int32_t* __restrict__ row_vid, int B) {
+  for (int b = blockIdx.x; b < B; b += gridDim.x)
+    for (int r = vid_sub_off[b] + threadIdx.x; r < vid_sub_off[b + 1]; r += blockDim.x) row_vid[r] = b;
 }
 
 // one thread per output frame (video b, frame f): walk the video's subtitles in row order, their frame lists in slot
@@ -65,15 +98,27 @@ __global__ void frame_map_kernel(const int32_t* __restrict__ vid_sub_off, const 
 using namespace hero;
 
 extern "C" int hero_collate_subs(const int32_t* sub_nfrm, const int32_t* sub_ntok, int64_t* gather_index, int64_t* attn_mask, int T,
-                                 int max_vl, int max_sl, hero_stream_t stream) {
+                                 int max_vl, int out_size, hero_stream_t stream) {
   HERO_REQUIRE(sub_nfrm && sub_ntok && gather_index && attn_mask, "hero_collate_subs: null pointer");
-  HERO_REQUIRE(T >= 0 && max_vl > 0 && max_sl > 0, "hero_collate_subs: bad dims");
+  HERO_REQUIRE(T >= 0 && max_vl > 0 && out_size > 0, "hero_collate_subs: bad dims");
   if (T == 0) return HERO_OK;
-  const size_t n = (size_t)T * (max_vl + max_sl);
+  const size_t n = (size_t)T * out_size;
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(collate_subs_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), sub_nfrm, sub_ntok, gather_index,
-                     attn_mask, T, max_vl, max_sl);
+                     attn_mask, T, max_vl, out_size);
   return check_launch("hero_collate_subs");
+}
+
+extern "C" int hero_collate_gather_feats(const float* c_v_feats, float* f_v_feats, const int32_t* vid_sub_off, const int32_t* vid_nfrm,
+                                         const int32_t* sub_frm_off, const int32_t* sub_frm, int32_t* row_vid, int T, int max_vl, int B,
+                                         int NF, int D, hero_stream_t stream) {
+  HERO_REQUIRE(c_v_feats && f_v_feats && vid_sub_off && vid_nfrm && sub_frm_off && sub_frm && row_vid, "hero_collate_gather_feats: null pointer");
+  HERO_REQUIRE(T > 0 && max_vl > 0 && B > 0 && NF > 0 && D > 0 && D % 4 == 0, "hero_collate_gather_feats: bad dims (D must be a multiple of 4)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(row_video_kernel, dim3(B < 1024 ? B : 1024), dim3(64), 0, s, vid_sub_off, row_vid, B);
+  hipLaunchKernelGGL(gather_feats_kernel, dim3(T * max_vl), dim3(256), 0, s, reinterpret_cast<const float4*>(c_v_feats),
+                     reinterpret_cast<float4*>(f_v_feats), row_vid, vid_nfrm, sub_frm_off, sub_frm, max_vl, NF, D / 4);
+  return check_launch("hero_collate_gather_feats");
 }
 
 extern "C" int hero_collate_clip_mask(const int32_t* vid_nfrm, int64_t* attn_mask, int B, int NF, hero_stream_t stream) {

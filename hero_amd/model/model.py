@@ -88,6 +88,9 @@ def build_frame_map(num_subs, sub_idx2frame_idx, n_videos, n_frames, seq_len, de
                 src.append(row + j)
         base += n
     total_src = base * seq_len
+    if any(not 0 <= f < n_frames for _, rows in enumerate(sub_idx2frame_idx) for _, fr in rows for f in fr):
+        raise IndexError("sub_idx2frame_idx names a frame outside [0, %d): the reference's index_put in "
+                         "collect_frame_outputs (model/model.py:183) fails on it too" % n_frames)
     dst = np.asarray(dst, dtype=np.int64)
     src = np.asarray(src, dtype=np.int64)
     order = np.argsort(dst, kind="stable")

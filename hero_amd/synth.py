@@ -14,60 +14,24 @@ SHAPES = {
 }
 
 
-def gather_index(txt_lens, v_lens, max_vl, out_size):
-    """data/data.py:504-512."""
-    n = len(txt_lens)
-    gi = torch.arange(out_size, dtype=torch.long).unsqueeze(0).repeat(n, 1)
-    for i, (tl, nf) in enumerate(zip(txt_lens, v_lens)):
-        gi[i, nf:nf + tl] = torch.arange(max_vl, max_vl + tl)
-    return gi
-
-
 def video_batch(subs, n_frames, vfeat_dim, vocab, gen, max_frames=None):
-    """subs: per video a list of (frame index list, n_tokens incl. SEP)."""
-    rows_v, rows_t = [], []
-    for vs in subs:
-        for fr, nt in vs:
-            rows_v.append(max(len(fr), 1))
-            rows_t.append(nt)
-    T, max_vl, max_sl = len(rows_v), max(rows_v), max(rows_t)
-    B, max_f = len(subs), max_frames or max(n_frames)
-    c_v = torch.zeros(B, max_f, vfeat_dim)
-    c_m = torch.zeros(B, max_f, dtype=torch.long)
-    for b, nf in enumerate(n_frames):
-        c_v[b, :nf] = torch.randn(nf, vfeat_dim, generator=gen)
-        c_m[b, :nf] = 1
-    ids = torch.ones(T, max_sl, dtype=torch.long)
-    f_v = torch.zeros(T, max_vl, vfeat_dim)
-    f_m = torch.zeros(T, max_vl + max_sl, dtype=torch.long)
-    sub2frm, num_subs, r = [], [], 0
-    for b, vs in enumerate(subs):
-        cur = []
-        for sid, (fr, nt) in enumerate(vs):
-            ids[r, 0] = 2
-            if nt > 1:
-                ids[r, 1:nt] = torch.randint(3, vocab, (nt - 1,), generator=gen)
-            if len(fr):
-                f_v[r, :len(fr)] = c_v[b, fr]
-                f_m[r, :len(fr) + nt] = 1
-            else:                                   # data/data.py:380-382
-                f_m[r, 1:1 + nt] = 1
-            cur.append((sid, list(fr)))
-            r += 1
-        sub2frm.append(cur)
-        num_subs.append(len(vs))
-    return {
-        "f_sub_input_ids": ids,
-        "f_sub_pos_ids": torch.arange(max_sl).clamp(max=511).unsqueeze(0),
-        "f_v_feats": f_v,
-        "f_v_pos_ids": torch.arange(max_vl).unsqueeze(0),
-        "f_attn_masks": f_m,
-        "f_gather_index": gather_index(rows_t, rows_v, max_vl, max_vl + max_sl),
-        "c_v_feats": c_v,
-        "c_attn_masks": c_m,
-        "num_subs": num_subs,
-        "sub_idx2frame_idx": sub2frm,
-    }
+    """subs: per video a list of (frame index list, n_tokens incl. SEP).  Random features / tokens pushed through
+    the collate of hero_amd.collate (== the reference's, tests/test_cpu_collate.py).  max_frames: pad the clip
+    stream to a fixed number of frames (same-shape batches for hipGraph replay)."""
+    from .collate import video_collate, video_item
+    items = []
+    for vs, nf in zip(subs, n_frames):
+        v_feat = torch.randn(nf, vfeat_dim, generator=gen)
+        toks = [torch.randint(3, vocab, (nt - 1,), generator=gen).tolist() for _, nt in vs]
+        items.append(video_item(v_feat, [(sid, list(fr)) for sid, (fr, _) in enumerate(vs)], toks, sep=2))
+    batch = video_collate(items)
+    NF = batch["c_v_feats"].shape[1]
+    if max_frames and max_frames > NF:
+        pad = max_frames - NF
+        batch["c_v_feats"] = torch.nn.functional.pad(batch["c_v_feats"], (0, 0, 0, pad))
+        batch["c_attn_masks"] = torch.nn.functional.pad(batch["c_attn_masks"], (0, pad))
+        batch["c_pos_ids"] = torch.arange(max_frames, dtype=torch.long).repeat(len(subs), 1)
+    return batch
 
 
 def query_batch(n, lens, vocab, gen):

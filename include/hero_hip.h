@@ -428,9 +428,16 @@ int hero_cross_entropy_bwd(const HeroCrossEntropy* a, hero_stream_t stream);
 /* arrays (data/data.py:406-512 video_collate + get_gather_index; the python walk of             */
 /* sub_idx2frame_idx in model/model.py:156-187).  All arrays int32 on the device.                */
 /* ------------------------------------------------------------------------------------------ */
-/* gather_index / attn_mask [T, max_vl + max_sl] int64 (data/data.py:504-512, 380-382) */
+/* gather_index / attn_mask [T, out_size] int64 (data/data.py:504-512, 380-382); out_size is the reference's  */
+/* f_attn_masks width = max over rows of (frame slots + tokens) (data/data.py:433-436), <= max_vl + max_sl   */
 int hero_collate_subs(const int32_t* sub_nfrm, const int32_t* sub_ntok, int64_t* gather_index, int64_t* attn_mask, int T,
-                      int max_vl, int max_sl, hero_stream_t stream);
+                      int max_vl, int out_size, hero_stream_t stream);
+/* f_v_feats [T, max_vl, D] fp32 <- c_v_feats [B, NF, D]: the per-subtitle frame feature copies of            */
+/* VideoFeatSubTokDataset.__getitem__ (data/data.py:371-379: frames outside [0, vid_nfrm) dropped, zero rows   */
+/* after the kept ones) made on the device; row_vid [T] is scratch (video of each subtitle row).  D % 4 == 0.  */
+int hero_collate_gather_feats(const float* c_v_feats, float* f_v_feats, const int32_t* vid_sub_off, const int32_t* vid_nfrm,
+                              const int32_t* sub_frm_off, const int32_t* sub_frm, int32_t* row_vid, int T, int max_vl, int B, int NF,
+                              int D, hero_stream_t stream);
 /* attn_mask [B, NF] int64 = f < vid_nfrm[b] */
 int hero_collate_clip_mask(const int32_t* vid_nfrm, int64_t* attn_mask, int B, int NF, hero_stream_t stream);
 /* Frame map of collect_frame_outputs, two passes around an exclusive scan done by the caller:       */

@@ -1,7 +1,9 @@
 """Collate on the device: the index tensors hero_amd.collate.DeviceCollate derives from length
-arrays equal, bit for bit, the ones hero_amd/synth.py builds on the host the way the reference's collate does
-(data/data.py:406-512) and the frame map of hero_amd.model.model.build_frame_map; the model gives identical
-outputs from either; a captured hipGraph replays on a NEW batch written into the static buffers."""
+arrays equal, bit for bit, the ones the REFERENCE's collate produced (tests/golden/case_collate.npz, written by the
+reference's own video_collate / get_gather_index, incl. batches narrower than max_vl + max_sl) and the frame map of
+hero_amd.model.model.build_frame_map; the HIP model on the reference-shaped narrow batch gives the reference model's
+outputs; the model gives identical outputs from host- and device-collated batches; a captured hipGraph replays on a
+NEW batch written into the static buffers."""
 import numpy as np
 import pytest
 import torch
@@ -10,11 +12,86 @@ pytestmark = pytest.mark.gpu
 
 
 def _lengths(batch):
-    from hero_amd.collate import lengths_from_lists
-    ids = batch["f_sub_input_ids"]
-    ntok = (ids != 1).sum(1).tolist()                               # pad id 1 (synth.video_batch)
-    nfr = batch["c_attn_masks"].sum(1).tolist()
-    return lengths_from_lists(batch["num_subs"], batch["sub_idx2frame_idx"], ntok, nfr)
+    return batch["lengths"]
+
+
+def _cases():
+    import json
+    import os
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "case_collate.npz"))
+    return json.loads(str(z["__cases__"]))
+
+
+@pytest.mark.parametrize("case", _cases())
+def test_device_collate_equals_reference_collate(case):
+    """Reference batch (fixture) vs DeviceCollate fed with the ~1 KB of lengths + c_v_feats only."""
+    from hero_amd.collate import DeviceCollate
+    from hero_amd.model.model import build_frame_map
+    from tests.test_cpu_collate import rebuild
+    mine, want = rebuild(case)                       # host half == fixture is the CPU test; lengths come from it
+    D = want["c_v_feats"].shape[2]
+    dc = DeviceCollate.for_batch(mine, "cuda", vfeat_dim=D if D % 4 == 0 else None)
+    assert dc.Lf == want["f_attn_masks"].shape[1]
+    dc.update(mine["lengths"], c_v_feats=want["c_v_feats"].cuda() if D % 4 == 0 else None)
+    torch.cuda.synchronize()
+    assert torch.equal(dc.f_gather_index.cpu(), want["f_gather_index"])
+    assert torch.equal(dc.f_attn_masks.cpu(), want["f_attn_masks"])
+    assert torch.equal(dc.c_attn_masks.cpu(), want["c_attn_masks"])
+    if D % 4 == 0:
+        assert torch.equal(dc.f_v_feats.cpu(), want["f_v_feats"])
+    B, NF = want["c_attn_masks"].shape
+    if all(0 <= f < NF for rows in want["sub_idx2frame_idx"] for _, fr in rows for f in fr):
+        offs, ent, inv = build_frame_map(want["num_subs"], want["sub_idx2frame_idx"], B, NF, dc.Lf, "cpu")
+        assert torch.equal(dc.offsets.cpu(), offs)
+        nnz = int(offs[-1])
+        assert torch.equal(dc.entries.cpu()[:nnz], ent[:nnz])
+        assert torch.equal(dc.inverse.cpu(), inv)
+
+
+@pytest.mark.parametrize("device_collated", [False, True])
+def test_hip_model_on_the_reference_narrow_batch(device_collated):
+    """The reference model's outputs on a batch its own collate produced with f_attn_masks NARROWER than
+    max_vl + max_sl (and a zero-frame subtitle, uncovered frames, a clipped video): fp32 HIP path within 2e-4."""
+    import os
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.collate import DeviceCollate
+    from hero_amd.utils.misc import set_dropout
+    from tests.test_cpu_collate import Z, rebuild
+    from tests.util import load_tiny, rel_err, to_dev
+    hero_amd.set_compute_dtype(torch.float32)
+    HF.set_grad_sink(None)
+    try:
+        model, _, _ = load_tiny("cuda")
+        model.eval()
+        mine, want = rebuild("narrow")
+        b = to_dev({k: v for k, v in want.items() if k != "vids"}, "cuda")
+        if device_collated:
+            dc = DeviceCollate.for_batch(mine, "cuda", vfeat_dim=want["c_v_feats"].shape[2])
+            dc.update(mine["lengths"], c_v_feats=b["c_v_feats"])
+            b.update(dc.batch_entries())
+            b.pop("num_subs"), b.pop("sub_idx2frame_idx")
+        W = want["f_attn_masks"].shape[1]
+        assert W < want["f_v_feats"].shape[1] + want["f_sub_input_ids"].shape[1]
+        with torch.no_grad():
+            f_seq = model.v_encoder.f_encoder(b, "repr")[0]
+            rep = model.v_encoder(b, "repr")
+            txt = model.v_encoder.f_encoder({"input_ids": b["query_input_ids"], "pos_ids": b["query_pos_ids"],
+                                             "attn_masks": b["query_attn_masks"]}, "txt")[0]
+        assert f_seq.shape == (want["f_attn_masks"].shape[0], W, 128)
+        t = lambda k: torch.from_numpy(Z["narrow.model." + k])      # noqa: E731
+        assert rel_err(f_seq, t("f_seq"), want["f_attn_masks"]) < 2e-4
+        assert rel_err(rep, t("repr"), want["c_attn_masks"]) < 2e-4
+        assert rel_err(txt, t("txt"), want["query_attn_masks"]) < 2e-4
+        model.train()
+        set_dropout(model, 0.0)
+        with torch.no_grad():
+            losses = model(b, task="tvr", compute_loss=True)
+        for got, key in zip(losses, ("loss_st_ed", "loss_neg_ctx", "loss_neg_q")):
+            np.testing.assert_allclose(got.cpu().numpy(), Z["narrow.model." + key], rtol=2e-4, atol=1e-6)
+    finally:
+        hero_amd.set_compute_dtype(torch.bfloat16)
 
 
 @pytest.mark.parametrize("ragged", [False, True])
@@ -23,15 +100,14 @@ def test_device_collate_equals_host_collate(ragged):
     from hero_amd.model.model import build_frame_map
     from hero_amd.synth import make_batch
     b = make_batch("D2", vfeat_dim=64, vocab=512, seed=3, ragged=ragged, videos=6)
-    T, max_vl = b["f_v_feats"].shape[:2]
-    max_sl = b["f_sub_input_ids"].shape[1]
     B, NF = b["c_attn_masks"].shape
-    dc = DeviceCollate(T, max_vl, max_sl, B, NF, "cuda").update(_lengths(b))
+    dc = DeviceCollate.for_batch(b, "cuda", vfeat_dim=64).update(_lengths(b), c_v_feats=b["c_v_feats"].cuda())
     torch.cuda.synchronize()
     assert torch.equal(dc.f_gather_index.cpu(), b["f_gather_index"])
     assert torch.equal(dc.f_attn_masks.cpu(), b["f_attn_masks"])
     assert torch.equal(dc.c_attn_masks.cpu(), b["c_attn_masks"])
-    offs, ent, inv = build_frame_map(b["num_subs"], b["sub_idx2frame_idx"], B, NF, max_vl + max_sl, "cpu")
+    assert torch.equal(dc.f_v_feats.cpu(), b["f_v_feats"])
+    offs, ent, inv = build_frame_map(b["num_subs"], b["sub_idx2frame_idx"], B, NF, dc.Lf, "cpu")
     assert torch.equal(dc.offsets.cpu(), offs)
     nnz = int(offs[-1])
     assert torch.equal(dc.entries.cpu()[:nnz], ent[:nnz])
@@ -49,9 +125,7 @@ def test_model_output_identical_with_device_collated_batch():
     model, _, _ = load_tiny("cuda")
     model.eval()
     b = make_batch("D1", vfeat_dim=96, vocab=160, seed=4, ragged=True, videos=3)
-    T, max_vl = b["f_v_feats"].shape[:2]
-    B, NF = b["c_attn_masks"].shape
-    dc = DeviceCollate(T, max_vl, b["f_sub_input_ids"].shape[1], B, NF, "cuda").update(_lengths(b))
+    dc = DeviceCollate.for_batch(b, "cuda").update(_lengths(b))
     d = to_dev(b, "cuda")
     d2 = dict(d)
     d2.update(dc.batch_entries())
@@ -118,9 +192,7 @@ def test_graph_replays_a_new_batch_written_into_the_static_buffers():
         HF.set_grad_sink(None)
 
         model = fresh()
-        T, max_vl = b1["f_v_feats"].shape[:2]
-        B, NF = b1["c_attn_masks"].shape
-        dc = DeviceCollate(T, max_vl, b1["f_sub_input_ids"].shape[1], B, NF, "cuda").update(_lengths(b1))
+        dc = DeviceCollate.for_batch(b1, "cuda").update(_lengths(b1))
         static = to_dev(b1, "cuda")
         static.update(dc.batch_entries())
         static.pop("num_subs"), static.pop("sub_idx2frame_idx")

@@ -613,6 +613,7 @@ extern "C" int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   return a->dtype == HERO_BF16 ? run<bf16_t>(*a, true, s) : run<float>(*a, true, s);
 }
+extern "C" int hero_attention_max_packed_len(int dtype) { return dtype == HERO_BF16 && use_mfma() ? 256 : 64; }
 extern "C" int hero_attention_max_len(int dtype, int backward) {
   if (dtype == HERO_BF16 && use_mfma()) return 256;       // matrix-core kernels (the backward wants a.ctx beyond 64)
   return dtype == HERO_BF16 ? max_len<bf16_t>(backward) : max_len<float>(backward);

@@ -296,7 +296,7 @@ class BertEncoder(nn.Module):
         plan = None
         if self.pack_ragged and BertEncoder.allow_packing and all(m is not None for m in mask_list) and x.is_cuda:
             plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs],
-                                   max_len=256 if cd == torch.bfloat16 else 64)
+                                   max_len=L.lib().hero_attention_max_packed_len(L.BF16 if cd == torch.bfloat16 else L.F32))
         if plan is not None:
             gather, inverse, inv, back, off, n_seq, lmax = plan
             x = HF.PermuteRowsFn.apply(x.contiguous(), gather, inverse)

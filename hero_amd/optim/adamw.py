@@ -26,7 +26,18 @@ class AdamW(Optimizer):
         if len(self.param_groups) > 8:
             raise ValueError("hero_amd AdamW supports up to 8 parameter groups")
         self._global_step = 0
-        self._tables = {}         # signature -> (device tensors, n_chunks); kept alive: captured graphs hold their pointers
+        self._tables = {}         # signature -> (device tensors, n_chunks)
+        self._pinned = []         # tables built or used while a hipGraph was capturing: the graph holds their addresses
+
+    def load_state_dict(self, state_dict):
+        """A restore replaces the moment tensors the descriptor tables point at: drop the tables (the ones captured
+        graphs use stay alive in `_pinned`, but such graphs must be re-captured - TrainStep refuses the restore)."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables, self._pinned = {}, []
 
     # ---- gradient norm ---------------------------------------------------------------------------
     def grad_sumsq(self, flat=None):
@@ -88,12 +99,15 @@ class AdamW(Optimizer):
                 active.append((gi, p))
         if not active:
             return loss
-        sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self._global_step - self.state[p]["step"])
-                    for _, p in active)
+        sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                     self.state[p]["exp_avg_sq"].data_ptr(), self._global_step - self.state[p]["step"]) for _, p in active)
+        capturing = torch.cuda.is_current_stream_capturing()
         if sig not in self._tables:
-            if len(self._tables) >= 16 and not torch.cuda.is_current_stream_capturing():
-                self._tables.clear()              # eager multi-task runs change the signature often
+            if len(self._tables) >= 16 and not capturing:
+                self._tables = {}                 # eager multi-task runs change the signature often; pinned tables survive
             self._tables[sig] = self._build_table(active)
+        if capturing and not any(t is self._tables[sig] for t in self._pinned):
+            self._pinned.append(self._tables[sig])
         raw, t_ct, t_ci, n_chunks = self._tables[sig]
         a = L.AdamWMulti()
         a.descs, a.chunk_tensor, a.chunk_index, a.n_chunks = raw.data_ptr(), t_ct.data_ptr(), t_ci.data_ptr(), n_chunks

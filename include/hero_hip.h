@@ -182,6 +182,9 @@ typedef struct HeroAttn {
 int hero_attention_fwd(const HeroAttn* a, hero_stream_t stream);
 int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream);
 int hero_attention_max_len(int dtype, int backward);
+/* longest sequence of a PACKED (seq_off) batch the kernels take for this dtype: 256 on the bf16 matrix-core */
+/* kernels, 64 otherwise (fp32, or HERO_ATTN_MFMA=0) - callers fall back to the padded layout beyond it      */
+int hero_attention_max_packed_len(int dtype);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row gathers / scatters                                                                       */

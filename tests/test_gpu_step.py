@@ -111,3 +111,43 @@ def test_one_launch_weight_refresh_equals_per_tensor_casts():
         torch.testing.assert_close(HF.packed(bs, torch.float32), torch.cat([p.detach() for p in bs]), rtol=0, atol=0)
     finally:
         HF.clear_weight_cache()
+
+
+def test_checkpoint_restore_after_steps_matches_uninterrupted_run():
+    """optimiser.load_state_dict replaces the moment tensors; the AdamW descriptor tables must not
+    keep pointing at the old ones.  save -> 2 more optimiser steps -> restore -> the same 2 steps == the first time."""
+    import copy
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.step import TrainStep
+    from hero_amd.utils.misc import set_dropout
+    hero_amd.set_compute_dtype(torch.float32)
+    HF.clear_weight_cache()
+    try:
+        model, _, _ = load_tiny("cuda")
+        model.train()
+        set_dropout(model, 0.0)
+        batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_train.npz"))
+        b = to_dev(batch, "cuda")
+        ts = TrainStep(model, opts=dict(learning_rate=1e-3, warmup_steps=2, num_train_steps=100))
+        for _ in range(4):
+            ts.micro_step(b)
+        saved_model = copy.deepcopy(model.state_dict())
+        saved_train = copy.deepcopy(ts.state_dict())
+        first = [float(ts.micro_step(b)) for _ in range(4)]
+        after_first = {k: v.detach().clone() for k, v in model.named_parameters()}
+        model.load_state_dict(saved_model)
+        ts.load_state_dict(saved_train)
+        second = [float(ts.micro_step(b)) for _ in range(4)]
+        import numpy as np
+        np.testing.assert_allclose(second, first, rtol=1e-4)          # split-K atomics reorder fp32 additions
+        for k, v in model.named_parameters():
+            assert rel_err(v, after_first[k]) < 1e-4, k
+        # the restored moments are the ones being updated (not the freed pre-restore buffers)
+        p = dict(model.named_parameters())["video_query_linear.weight"]
+        st = ts.optimizer.state[p]
+        assert float(st["exp_avg"].abs().sum()) > 0 and st["step"] == 4
+    finally:
+        HF.set_grad_sink(None)
+        HF.clear_weight_cache()
+        hero_amd.set_compute_dtype(torch.bfloat16)

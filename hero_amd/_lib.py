@@ -16,7 +16,7 @@ LAYOUT_K, LAYOUT_O = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
+    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
@@ -158,6 +158,8 @@ def lib():
         L.hero_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [
             C.POINTER(GemmEpilogue), C.c_void_p]
         L.hero_wgrad_group.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hero_wgrad_batch_plan.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.hero_wgrad_batch.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.hero_prof_enable.argtypes = [C.c_int]
         L.hero_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_longlong)]

@@ -41,6 +41,8 @@
 // (the swizzle is applied on the SOURCE address of the DMA and on the read address).
 // Reduction tail of the O,O flavour (rows % 64 != 0): the loads of rows past the matrix are
 // out-of-range for the buffer descriptor and deliver zeros.
+#include <vector>
+
 #include "gemm_args.h"
 
 namespace hero {
@@ -58,6 +60,24 @@ constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-
 #define HERO_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Scheduling pattern of a region that holds NM MFMAs and ND LDS reads (ND <= 2 NM): MFMA, PER reads, MFMA, PER reads, ...
+// (sched_group_barrier masks: 0x008 MFMA, 0x100 DS read).  HERO_WS_BLOCKED restores the round-2 order for A/B runs.
+template <int NM, int ND, int PER>
+__device__ __forceinline__ void ws_interleave() {
+#ifndef HERO_WS_BLOCKED
+  if constexpr (NM > 0) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (ND >= PER) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+    else if constexpr (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+    ws_interleave<NM - 1, (ND >= PER ? ND - PER : 0), PER>();
+  }
+#else
+  __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+#endif
+}
+#define WS_INTERLEAVE(NM, ND) ws_interleave<(NM), (ND), ((ND) > (NM) ? 2 : 1)>()
 
 #ifdef HERO_WS_TRACE
 // timeline probe (tools/lab/trace_ws.py): s_memtime stamps of the first four items of workgroup 0, per wave
@@ -214,7 +234,13 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
   constexpr int TM = G::TM, TN = G::TN, BN = G::BN, RPP = G::RPP, C8 = G::C8, RPI = G::RPI, ITERS = G::ITERS;
   const HeroGemmEpilogue& e = g.epi;
   char* st = smem + slot;
-  const int tid = threadIdx.x;
+  // Everything the epilogue derives from the thread index is recomputed per tile from an opaque copy: hoisted out of the
+  // item loop these values stay live across the main loop, where 144 accumulators + 48 fragment registers leave no room,
+  // and get spilled to scratch (a reload = one memory round trip at the start of every epilogue).
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c8 = tid % C8, r0 = tid / C8;
   const bool active = r0 < RPI;
   const int gn = ic.n0 + c8 * 8;
@@ -496,24 +522,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       curo += G::STAGE;
       if (curo == NS * G::STAGE) curo = 0;
       const char* nxt = smem + curo;
+      // one scheduling region per 16-k slice: the fragment reads of the NEXT slice are spread between the MFMAs of the
+      // current one (round 3; as a block in front of them they cost MFMA-idle issue time, see gemm_wsb_kernel)
+      constexpr int NRD = TR ? 2 * (TM + TN) : TM + TN;
       ldf(a1, b1, cur, 1);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
+      WS_INTERLEAVE(TM * TN, NRD);
       __builtin_amdgcn_sched_barrier(0);
       ldf(a0, b0, cur, 2);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a1, b1);
+      WS_INTERLEAVE(TM * TN, NRD);
       __builtin_amdgcn_sched_barrier(0);
       ldf(a1, b1, cur, 3);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
+      WS_INTERLEAVE(TM * TN, NRD);
       __builtin_amdgcn_sched_barrier(0);
       wait_lds();
       __builtin_amdgcn_s_barrier();                                   // B(u): done reading `cur`, stage u+1 landed
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < ic.nk || (TR && more_items)) ldf(a0, b0, nxt, 0);   // K,K: the next item's first slice is read after the epilogue
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a1, b1);
+      ldf(a0, b0, nxt, 0);            // unconditional: behind an item's last step it reads the next item's landed first
+      mma(a1, b1);                    // stage (K,K: read again after the epilogue) or stale LDS, never used
+      WS_INTERLEAVE(TM * TN, NRD);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!TR) {
@@ -725,23 +754,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (curo == NS * G::STAGE) curo = 0;
       const char* nxt = smem + curo;
       ldf(a1, b1, cur, 1);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       ldf(a0, b0, cur, 2);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a1, b1);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       ldf(a1, b1, cur, 3);
-      __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       wait_lds();
       __builtin_amdgcn_s_barrier();                                   // B(u)
       __builtin_amdgcn_sched_barrier(0);
-      if (pos + t + 1 < end) ldf(a0, b0, nxt, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      ldf(a0, b0, nxt, 0);            // unconditional (stale LDS behind the range's last step, never used)
       mma(a1, b1);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
     }
     pos += sg.nk;
@@ -762,6 +791,361 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     WS_T(seg_no, 14, wave, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched wgrad, whole tiles (round 3): up to 32 problems dW_p += dY_p^T X_p that reduce over the SAME rows - the weight
+// gradients of ALL the BertLayers of an encoder (6 x (64 + 64 + 16 + 48) = 1152 tiles of 192 x 192 over 12000 rows =
+// 4.5 rounds of 256 CUs) - in ONE launch, scheduled by a host-built plan (hero_wgrad_batch_plan):
+//   * full rounds: every workgroup owns WHOLE tiles (all k-steps), so there is no merge: dW += acc is a plain fp32
+//     read-add-write of the tile, bit-reproducible.  All workgroups start their tiles at k = 0 together and the 32 tiles
+//     of an XCD in a round are a compact patch of ONE problem (8 x 4 tiles: 12 distinct operand panels instead of 64), so
+//     concurrent tiles share their panels in the XCD's L2 (the stream-K ranges of gemm_wsg_kernel start at staggered k
+//     offsets and share nothing: 765 MB of fabric traffic per launch against 320 MB algorithmic);
+//   * tail round (tiles % 256 != 0): the remaining tiles are cut into S k-slices so that tiles x S fills the chip; the
+//     slices of a tile add to dW with fp32 atomics IN SLICE ORDER (a per-tile flag: slice s waits until slice s - 1 has
+//     drained its atomics), which keeps the sum bit-reproducible.
+// Same ring / wave roles / O,O LDS images as gemm_ws_kernel<3, 3, true>; the MFMA operands are swapped (acc = dW^T
+// fragments: lane <-> output row) so that the accumulators are staged through LDS with ds_write_b128 and all eight
+// waves update full rows of dW with 16-byte accesses.
+// ------------------------------------------------------------------------------------------------
+struct WsbProb {
+  const bf16_t* A;      // dY [K, lda], M columns from the pointer on
+  const bf16_t* B;      // X  [K, ldb], N columns
+  float* C;             // dW [M, ldc]
+  int M, N, lda, ldb, ldc, pad_;
+};
+struct WsbItem { int prob, m0, n0, k0, nk, order, nslices, flag; };     // nk == 0: the slot is idle in this round
+struct WsbArgs {
+  const WsbItem* items;   // [rounds][nwg]
+  int* flags;             // slice-order flags of the tail tiles (zero between launches)
+  int rounds, K, nprob, pad_;
+  WsbProb p[HERO_WGRAD_BATCH_MAX];
+};
+
+template <typename G, bool COMPUTE>
+__device__ __forceinline__ void epilogue_acc(const WsbProb& P, const WsbItem& it, int* flags, char* smem, unsigned slot,
+                                             f32x16_t (*acc)[G::TN], int wave, int lane) {
+  constexpr int TM = G::TM, TN = G::TN, BN = G::BN, RPP = G::RPP, C8 = G::C8, RPI = G::RPI, ITERS = G::ITERS;
+  char* st = smem + slot;
+  int tid = threadIdx.x;                             // opaque copy: see epilogue_rows
+  asm volatile("" : "+v"(tid));
+  lane = tid & 63;
+  wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c8 = tid % C8, r0 = tid / C8;
+  const int gn = it.n0 + c8 * 8;
+  const bool col_ok = r0 < RPI && gn < P.N;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+  const bool plain = it.nslices == 1;                                 // uniform
+  constexpr bool SPLIT = (RPP == 64 && G::PASSES == TM);
+  auto tile_row = [](int p, int row) { return SPLIT ? (row >> 5) * (TM * 32) + p * 32 + (row & 31) : p * RPP + row; };
+  // dW through a buffer descriptor: masked-off lanes get an out-of-range offset (loads return 0, stores are dropped),
+  // so every access of a pass is issued back to back in straight-line code (a branch per store makes hipcc wait for
+  // the previous store's round trip in every iteration: 58 us instead of 7 per tile)
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, 0x7ffffff0, 0x00020000);
+  if (!plain && it.order > 0) {
+    // earlier slices first: their atomics have drained (vmcnt(0) + barrier) before the flag moves
+    if (lane == 0)
+      while (__hip_atomic_load(flags + it.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it.order) __builtin_amdgcn_s_sleep(8);
+  }
+#pragma unroll
+  for (int p = 0; p < G::PASSES; ++p) {
+    u32x4_t old0[ITERS], old1[ITERS];
+    unsigned voff[ITERS];                            // byte offsets inside dW (< 2^31: checked by the launcher)
+    if (plain) {
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        const int row = r0 + i * RPI;
+        const int gm = it.m0 + tile_row(p, row);
+        const bool ok = col_ok && row < RPP && gm < P.M;
+        voff[i] = ok ? ((unsigned)gm * (unsigned)P.ldc + (unsigned)gn) * 4u : 0xfffffff0u;
+        // the tile's old values: in flight while the accumulators are staged
+#if defined(HERO_WSB_EPI_NOLOAD) || defined(HERO_WSB_EPI_NOMEM)
+        old0[i] = u32x4_t{0u, 0u, 0u, 0u};
+        old1[i] = u32x4_t{0u, 0u, 0u, 0u};
+#else
+        old0[i] = __builtin_amdgcn_raw_buffer_load_b128(rc, voff[i], 0, 0);
+        old1[i] = __builtin_amdgcn_raw_buffer_load_b128(rc, voff[i], 16, 0);
+#endif
+      }
+    }
+    if constexpr (COMPUTE) {
+#pragma unroll
+      for (int b = 0; b < RPP / 32; ++b) {
+        const int blk = SPLIT ? b * TM + p : p * (RPP / 32) + b;
+        if (wm == blk / TM) {
+          const int i = blk % TM;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int chunk = (wn * TN * 32 + j * 32 + 8 * q + 4 * half) >> 2;
+              const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              *reinterpret_cast<f32x4_t*>(st + (32 * b + l31) * G::ROWB + ((chunk ^ (l31 & 7)) << 4)) = v;
+            }
+        }
+      }
+    }
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                    // E1: the pass is staged
+    if (plain) {
+      // two iterations at a time (the staged values of all four would not fit beside 144 accumulators)
+#pragma unroll
+      for (int h = 0; h < ITERS; h += 2) {
+        f32x4_t v0[2], v1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = min(r0 + (h + i) * RPI, RPP - 1), x = row & 7;
+          v0[i] = *reinterpret_cast<const f32x4_t*>(st + row * G::ROWB + (((2 * c8) ^ x) << 4));
+          v1[i] = *reinterpret_cast<const f32x4_t*>(st + row * G::ROWB + (((2 * c8 + 1) ^ x) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v0[i][k] += __uint_as_float(old0[h + i][k]);
+            v1[i][k] += __uint_as_float(old1[h + i][k]);
+          }
+#ifdef HERO_WSB_EPI_NOMEM
+        asm volatile("" ::"v"(v0[0]), "v"(v1[0]), "v"(v0[1]), "v"(v1[1]));
+        continue;
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v0[i][0]), __float_as_uint(v0[i][1]), __float_as_uint(v0[i][2]), __float_as_uint(v0[i][3])}, rc, voff[h + i], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v1[i][0]), __float_as_uint(v1[i][1]), __float_as_uint(v1[i][2]), __float_as_uint(v1[i][3])}, rc, voff[h + i], 16, 0);
+        }
+      }
+    } else {
+      // k-slice of a tail tile: fp32 atomics, a lane per column (one instruction = 256 contiguous bytes of a row), two
+      // rows of the pass per iteration on waves 0-5
+      const int col = tid % BN, rr = tid / BN;       // rr 0..1 active (tid < 2 BN)
+      const int gc = it.n0 + col;
+      if (tid < 2 * BN && gc < P.N) {
+        const unsigned sw = (unsigned)(col >> 2);
+#pragma unroll 4
+        for (int q = 0; q < RPP / 2; ++q) {
+          const int row = 2 * q + rr;
+          const int gm = it.m0 + tile_row(p, row);
+          const float v = *reinterpret_cast<const float*>(st + row * G::ROWB + (((sw ^ (unsigned)(row & 7))) << 4) + (col & 3) * 4);
+          if (gm < P.M) atomicAdd(P.C + (size_t)gm * P.ldc + gc, v);
+        }
+      }
+      if (p == G::PASSES - 1) wait_vm<0>();          // this wave's atomics have been acknowledged
+    }
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                    // E2: the slot may be restaged / refilled
+  }
+  if (!plain && tid == 0)                            // every wave's atomics drained before E2: hand over / reset
+    __hip_atomic_store(flags + it.flag, it.order + 1 < it.nslices ? it.order + 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_wsb_kernel(WsbArgs g) {
+  typedef Geo<3, 3> G;
+  constexpr int TM = 3, TN = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  // the next busy round of this workgroup at or after r (rounds with an idle slot are skipped by all eight waves alike)
+  auto next_round = [&](int r) {
+    while (r < g.rounds && g.items[(size_t)r * nwg + wg].nk == 0) ++r;
+    return r;
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    const int w = wave - 4;
+    constexpr int CA = G::BM / 8, CB = G::BN / 8;
+    int lr = next_round(0), ik = 0, lnk = 0;       // round / stage being issued next
+    unsigned goa[G::PA], gob[G::PB];
+    const char* pa = nullptr;
+    const char* pb = nullptr;
+    unsigned ra_left = 0, rb_left = 0, sa = 0, sb = 0, fill = 0;
+    auto setup = [&]() {
+      const WsbItem it = g.items[(size_t)lr * nwg + wg];
+      const WsbProb& P = g.p[it.prob];
+      lnk = it.nk;
+#pragma unroll
+      for (int i = 0; i < G::PA; ++i) {
+        const int id = (w * G::PA + i) * 64 + lane, row = id / CA, c = (id % CA) ^ swz_o<G::BM * 2>(row);
+        goa[i] = (unsigned)row * (unsigned)P.lda * 2u + (c << 4);
+      }
+#pragma unroll
+      for (int i = 0; i < G::PB; ++i) {
+        const int id = (w * G::PB + i) * 64 + lane, row = id / CB, c = (id % CB) ^ swz_o<G::BN * 2>(row);
+        gob[i] = (unsigned)row * (unsigned)P.ldb * 2u + (c << 4);
+      }
+      const int kb = it.k0 * 64;
+      pa = reinterpret_cast<const char*>(P.A + (size_t)kb * P.lda + it.m0);
+      pb = reinterpret_cast<const char*>(P.B + (size_t)kb * P.ldb + it.n0);
+      ra_left = (unsigned)(((size_t)(g.K - kb) * P.lda - it.m0) * 2);
+      rb_left = (unsigned)(((size_t)(g.K - kb) * P.ldb - it.n0) * 2);
+      sa = 64u * (unsigned)P.lda * 2u;
+      sb = 64u * (unsigned)P.ldb * 2u;
+    };
+    if (lr < g.rounds) setup();
+    auto issue = [&]() -> bool {
+      if (lr >= g.rounds) return false;
+      char* buf = smem + fill;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, ra_left, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, rb_left, 0x00020000);
+#ifndef HERO_WSB_NOLOADS        // lab ablations (tools/lab/build_variants.sh): results are garbage, timing only
+#pragma unroll
+      for (int i = 0; i < G::PA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < G::PB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, 0);
+#else
+      (void)ra; (void)rb; (void)buf;
+#endif
+      fill += G::STAGE;
+      if (fill == NS * G::STAGE) fill = 0;
+      if (++ik == lnk) {
+        ik = 0;
+        lr = next_round(lr + 1);
+        if (lr < g.rounds) setup();
+      } else {
+        pa += sa; pb += sb;
+        ra_left = ra_left > sa ? ra_left - sa : 0u;
+        rb_left = rb_left > sb ? rb_left - sb : 0u;
+      }
+      return true;
+    };
+    issue();
+    const bool second = issue();
+    if (second) wait_vm<G::PW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                                     // B(-1): stage 0 landed
+    unsigned slot = 0;
+    for (int r = next_round(0); r < g.rounds; r = next_round(r + 1)) {
+      const WsbItem it = g.items[(size_t)r * nwg + wg];
+      for (int t = 0; t < it.nk; ++t) {
+        if (issue()) wait_vm<G::PW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                                 // B(u)
+        if (t + 1 < it.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
+      }
+#ifndef HERO_WSB_NOEPI
+      epilogue_acc<G, false>(g.p[it.prob], it, g.flags, smem, slot, nullptr, wave, lane);
+#endif
+      slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow0 = wm * TM * 32, brow0 = wn * TN * 32;
+  unsigned ao[TM], bo[TN];
+  {
+    const int p = lane & 15, gq = (lane >> 4) & 1, kg = lane >> 5;
+    const int krow = kg * 8 + (p >> 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int col = arow0 + i * 32 + gq * 16 + 4 * (p & 3);
+      ao[i] = krow * (G::BM * 2) + ((((col >> 3) ^ swz_o<G::BM * 2>(krow)) << 4) | ((col & 7) * 2));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = brow0 + j * 32 + gq * 16 + 4 * (p & 3);
+      bo[j] = G::A_BYTES + krow * (G::BN * 2) + ((((col >> 3) ^ swz_o<G::BN * 2>(krow)) << 4) | ((col & 7) * 2));
+    }
+  }
+  typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+  bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
+  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
+#ifdef HERO_WSB_NOLDF
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const char* q = st + ao[i] + ks * 16 * (G::BM * 2);
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BM * 2)));
+      a[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const char* q = st + bo[j] + ks * 16 * (G::BN * 2);
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BN * 2)));
+      b[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  f32x16_t acc[TM][TN];
+  auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
+#ifdef HERO_WSB_NOMFMA
+    asm volatile("" ::"v"(a[0]), "v"(b[0]), "v"(a[TM - 1]), "v"(b[TN - 1]));
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // dW^T: lane <-> output row
+  };
+  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_barrier();                                       // B(-1)
+  unsigned curo = 0;
+  int r = next_round(0);
+  if (r < g.rounds) ldf(a0, b0, smem, 0);
+  while (r < g.rounds) {
+    const WsbItem it = g.items[(size_t)r * nwg + wg];
+    const int rn = next_round(r + 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    unsigned last = curo;
+    for (int t = 0; t < it.nk; ++t) {
+      const char* cur = smem + curo;
+      last = curo;
+      curo += G::STAGE;
+      if (curo == NS * G::STAGE) curo = 0;
+      const char* nxt = smem + curo;
+      // One scheduling region per 16-k slice: the 12 transposing fragment reads of the NEXT slice are spread between
+      // the 9 MFMAs of the current one (MFMA, 2 reads, MFMA, 2 reads, ...).  Issued as a block in front of the MFMAs
+      // (round 2) the reads cost ~140 cycles of MFMA-idle issue time per slice: 0.89 us per 64-k step with the DMA
+      // switched off against 0.58 us of MFMA issue (tools/lab/wsb_sweep.py, noloads).
+      ldf(a1, b1, cur, 1);
+      mma(a0, b0);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a0, b0, cur, 2);
+      mma(a1, b1);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a1, b1, cur, 3);
+      mma(a0, b0);
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lds();
+      __builtin_amdgcn_s_barrier();                                   // B(u)
+      __builtin_amdgcn_sched_barrier(0);
+      ldf(a0, b0, nxt, 0);            // unconditional (a branch around it doubles the MFMA code and spills): after the
+      mma(a1, b1);                    // item's last step this reads the landed first stage of the next item and is
+      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));   // simply read again behind the epilogue
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#ifndef HERO_WSB_NOEPI
+    epilogue_acc<G, true>(g.p[it.prob], it, g.flags, smem, last, acc, wave, lane);
+#else
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+#endif
+    __builtin_amdgcn_s_setprio(2);
+    if (rn < g.rounds) ldf(a0, b0, smem + curo, 0);
+    r = rn;
   }
 }
 
@@ -954,4 +1338,118 @@ extern "C" int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int
     if (rc) return rc;
   }
   return HERO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hero_wgrad_batch: plan + launch (hero_hip.h)
+// ------------------------------------------------------------------------------------------------
+namespace hero {
+namespace ws {
+__device__ int g_wsb_flags[512];          // slice-order flags of the tail tiles; every launch leaves them zero
+constexpr int PLAN_MAGIC = 0x57534232;    // "WSB2"
+constexpr int PLAN_HDR = 8;               // words: magic, nwg, rounds, items, n problems, K, tiles, tail slices
+}  // namespace ws
+}  // namespace hero
+
+extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K, int32_t* plan, int capacity_words) {
+  using namespace hero;
+  using namespace hero::ws;
+  typedef Geo<3, 3> G;
+  HERO_REQUIRE(probs && n >= 1 && n <= HERO_WGRAD_BATCH_MAX, "hero_wgrad_batch_plan: 1..%d problems", HERO_WGRAD_BATCH_MAX);
+  HERO_REQUIRE(K >= 64, "hero_wgrad_batch_plan: K = %d", K);
+  const int nwg = num_cus(), ksteps = (K + 63) / 64;
+  if (nwg % 8 != 0) return 0;
+  // tiles in patch order: up to 8 x 4 (or tiles_m x 32 / tiles_m) tiles of one problem are consecutive = one XCD's round
+  struct T3 { int prob, mt, nt; };
+  std::vector<T3> tiles;
+  for (int i = 0; i < n; ++i) {
+    HERO_REQUIRE(probs[i].M > 0 && probs[i].N > 0 && probs[i].M % 8 == 0 && probs[i].N % 8 == 0, "hero_wgrad_batch_plan: bad problem %d", i);
+    const int tm = (probs[i].M + G::BM - 1) / G::BM, tn = (probs[i].N + G::BN - 1) / G::BN;
+    const int per = nwg / 8;
+    int pm = tm < 8 ? tm : 8;
+    int pn = per / pm > 0 ? per / pm : 1;
+    if (pn > tn) { pn = tn; pm = per / pn < tm ? per / pn : tm; if (pm < 1) pm = 1; }
+    for (int bm = 0; bm < tm; bm += pm)
+      for (int bn = 0; bn < tn; bn += pn)
+        for (int mi = bm; mi < bm + pm && mi < tm; ++mi)
+          for (int ni = bn; ni < bn + pn && ni < tn; ++ni) tiles.push_back({i, mi, ni});
+  }
+  const int T = (int)tiles.size();
+  const int full = T / nwg, rem = T % nwg;
+  if (full == 0) return 0;
+  const int rounds = full + (rem ? 1 : 0);
+  const int words = PLAN_HDR + rounds * nwg * 8;
+  HERO_REQUIRE(plan && capacity_words >= words, "hero_wgrad_batch_plan: needs %d words, capacity %d", words, capacity_words);
+  for (int i = PLAN_HDR; i < words; ++i) plan[i] = 0;
+  auto item = [&](int r, int w) { return plan + PLAN_HDR + ((size_t)r * nwg + w) * 8; };
+  for (int r = 0; r < full; ++r)
+    for (int w = 0; w < nwg; ++w) {
+      const T3& t = tiles[(size_t)r * nwg + w];
+      int32_t* q = item(r, w);
+      q[0] = t.prob; q[1] = t.mt * G::BM; q[2] = t.nt * G::BN; q[3] = 0; q[4] = ksteps; q[5] = 0; q[6] = 1; q[7] = 0;
+    }
+  int S = 1;
+  if (rem) {
+    const int per_xcd_cap = nwg / 8, per_xcd = (rem + 7) / 8;         // tail tiles per XCD
+    S = per_xcd_cap / per_xcd;
+    while (S > 1 && ksteps / S < 4) --S;
+    if (S > 8) S = 8;
+    HERO_REQUIRE(per_xcd <= 512 / 8, "hero_wgrad_batch_plan: flag capacity");
+    for (int j = 0; j < rem; ++j) {
+      const T3& t = tiles[(size_t)full * nwg + j];
+      const int xcd = j / per_xcd, loc = j % per_xcd;
+      for (int sl = 0; sl < S; ++sl) {
+        const int k0 = (int)((long long)ksteps * sl / S), k1 = (int)((long long)ksteps * (sl + 1) / S);
+        int32_t* q = item(full, xcd * per_xcd_cap + sl * per_xcd + loc);
+        q[0] = t.prob; q[1] = t.mt * G::BM; q[2] = t.nt * G::BN; q[3] = k0; q[4] = k1 - k0; q[5] = sl; q[6] = S;
+        q[7] = xcd * (512 / 8) + loc;
+      }
+    }
+  }
+  plan[0] = PLAN_MAGIC; plan[1] = nwg; plan[2] = rounds; plan[3] = rounds * nwg; plan[4] = n; plan[5] = K; plan[6] = T; plan[7] = S;
+  return words;
+}
+
+extern "C" int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int dtype, const int32_t* plan_dev, int plan_words,
+                                hero_stream_t stream) {
+  using namespace hero;
+  using namespace hero::ws;
+  typedef Geo<3, 3> G;
+  HERO_REQUIRE(probs && n >= 1 && n <= HERO_WGRAD_BATCH_MAX, "hero_wgrad_batch: 1..%d problems", HERO_WGRAD_BATCH_MAX);
+  HERO_REQUIRE(dtype == HERO_BF16, "hero_wgrad_batch: bf16 only (dtype %d)", dtype);
+  HERO_REQUIRE(plan_dev && plan_words > PLAN_HDR && (plan_words - PLAN_HDR) % (8 * num_cus()) == 0,
+               "hero_wgrad_batch: the plan (%d words) was not made for this device (%d workgroups)", plan_words, num_cus());
+  HERO_REQUIRE(((uintptr_t)plan_dev & 15) == 0, "hero_wgrad_batch: plan_dev must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WsbArgs g;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const HeroWgradProblem& q = probs[i];
+    HERO_REQUIRE(q.dy && q.x && q.dw && q.M > 0 && q.N > 0 && q.M % 8 == 0 && q.N % 8 == 0 && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 &&
+                     q.ld_dw % 4 == 0 && (((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dw) & 15) == 0 &&
+                     (size_t)K * q.ld_dy * 2 < 0xffffffffull && (size_t)K * q.ld_x * 2 < 0xffffffffull &&
+                     (size_t)q.M * q.ld_dw * 4 < 0x7ffffff0ull,
+                 "hero_wgrad_batch: problem %d is unaligned / too large", i);
+    WsbProb& P = g.p[i];
+    P.A = static_cast<const bf16_t*>(q.dy); P.B = static_cast<const bf16_t*>(q.x); P.C = q.dw;
+    P.M = q.M; P.N = q.N; P.lda = q.ld_dy; P.ldb = q.ld_x; P.ldc = q.ld_dw; P.pad_ = 0;
+    flops += 2.0 * q.M * (double)q.N * K;
+  }
+  for (int i = n; i < HERO_WGRAD_BATCH_MAX; ++i) g.p[i] = g.p[0];
+  g.items = reinterpret_cast<const WsbItem*>(plan_dev + PLAN_HDR);
+  g.rounds = (plan_words - PLAN_HDR) / (8 * num_cus());
+  g.K = K; g.nprob = n; g.pad_ = 0;
+  static int* flags = nullptr;             // resolved once, outside any stream capture of later calls
+  if (!flags) HERO_REQUIRE(hipGetSymbolAddress(reinterpret_cast<void**>(&flags), HIP_SYMBOL(hero::ws::g_wsb_flags)) == hipSuccess,
+                           "hero_wgrad_batch: flag storage");
+  g.flags = flags;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    attr_set = true;
+  }
+  void* tok = gemm_prof_begin(9, s);
+  hipLaunchKernelGGL(gemm_wsb_kernel, dim3(num_cus()), dim3(512), G::LDS, s, g);
+  gemm_prof_end(tok, flops, s);
+  return check_launch("hero_wgrad_batch");
 }

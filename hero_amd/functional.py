@@ -13,6 +13,7 @@ import ctypes as C
 import math
 import os
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -244,6 +245,11 @@ class GradSink:
     def done(self, p):
         pass
 
+    def wants_overlap(self):
+        """True when gradients should become final layer by layer during this backward pass (a bucketed all-reduce
+        is waiting for them): weight gradients are then launched per layer instead of per encoder."""
+        return False
+
 
 SINK = GradSink()
 
@@ -339,20 +345,46 @@ def _split_for(n_out, n_in, rows, bk):
 
 
 # Weight gradients that ACCUMULATE into the gradient sink are not launched one by one: inside a backward pass they
-# are queued and launched four at a time - the four nn.Linear weights of a BertLayer reduce over the same rows -
-# as ONE stream-K launch (hero_wgrad_group).  The queue is flushed when it holds four problems, when the row count
-# changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
+# are queued and launched together.  Round 3: the queue holds up to WGRAD_BATCH[0] problems - the weight gradients of
+# ALL the BertLayers of an encoder reduce over the same rows - and goes out as ONE whole-tile launch
+# (hero_wgrad_batch: 6 x 192 = 1152 tiles = 4.5 rounds of the chip, no atomics in the full rounds, bit-reproducible);
+# groups with fewer tiles than the chip has CUs, and the boundary micro-steps of a data-parallel run (where a layer's
+# gradients must become final - and their bucket's all-reduce start - while backward is still running), go four at a
+# time through the stream-K launch of round 2 (hero_wgrad_group).  The queue is flushed when it is full, when the row
+# count changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
 # pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
+# The queue keeps dY / X alive until then (~1 GB for HERO-base at 12000 rows).
 _WQ = []
 _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [os.environ.get("HERO_NOGROUP", "") == ""]      # HERO_NOGROUP=1: one launch per weight gradient (A/B runs)
+WGRAD_BATCH = [int(os.environ.get("HERO_WGRAD_BATCH", "32"))]   # 4: the per-layer stream-K launches of round 2
+_WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) or None when the group is too small
+
+
+def _wgrad_limit():
+    return 4 if (WGRAD_BATCH[0] <= 4 or SINK.wants_overlap()) else min(WGRAD_BATCH[0], 32)
+
+
+def _wgrad_plan(probs, n, rows, device):
+    key = (rows, device.index, tuple((probs[i].M, probs[i].N) for i in range(n)))
+    hit = _WPLANS.get(key, False)
+    if hit is False:
+        buf = np.zeros(8 + 8 * 512 * 16, dtype=np.int32)
+        words = L.lib().hero_wgrad_batch_plan(probs, n, rows, buf.ctypes.data, buf.size)
+        if words < 0:
+            L.check(words)
+        hit = (torch.from_numpy(buf[:words].copy()).to(device), words) if words > 0 else None
+        if len(_WPLANS) > 64:
+            _WPLANS.clear()
+        _WPLANS[key] = hit
+    return hit
 
 
 def wgrad_flush():
     while _WQ:
         rows, dtype = _WQ[0][0].shape[0], _WQ[0][0].dtype
         n = 1
-        while n < len(_WQ) and n < 4 and _WQ[n][0].shape[0] == rows and _WQ[n][0].dtype == dtype:
+        while n < len(_WQ) and n < 32 and _WQ[n][0].shape[0] == rows and _WQ[n][0].dtype == dtype:
             n += 1
         group, rest = _WQ[:n], _WQ[n:]
         del _WQ[:]
@@ -362,7 +394,13 @@ def wgrad_flush():
             K = x2.shape[1]
             probs[i] = L.WgradProblem(L.ptr(dy2) + col0 * dy2.element_size(), L.ptr(x2), L.ptr(out), N, K,
                                       dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32))
-        L.check(L.lib().hero_wgrad_group(probs, n, rows, L.dt(group[0][0]), L.stream()))
+        plan = _wgrad_plan(probs, n, rows, group[0][0].device) if (n > 4 and dtype == torch.bfloat16) else None
+        if plan is not None:
+            L.check(L.lib().hero_wgrad_batch(probs, n, rows, L.BF16, L.ptr(plan[0]), plan[1], L.stream()))
+        else:
+            for g0 in range(0, n, 4):
+                sub = (L.WgradProblem * min(4, n - g0))(*[probs[i] for i in range(g0, min(g0 + 4, n))])
+                L.check(L.lib().hero_wgrad_group(sub, len(sub), rows, L.dt(group[0][0]), L.stream()))
         for e in group:
             if e[5] is not None:
                 e[5]()
@@ -384,7 +422,7 @@ def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
             _WQ_TASK[0] = task
             torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
         _WQ.append((dy2, x2, out, col0, N, on_done))
-        if len(_WQ) == 4:
+        if len(_WQ) >= _wgrad_limit():
             wgrad_flush()
         return out
     if out is None:

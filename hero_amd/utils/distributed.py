@@ -256,6 +256,9 @@ class GradArena(HF.GradSink):
         self._final.clear()          # finality is per backward pass (accumulation adds to the same slots)
         self._uses.clear()
 
+    def wants_overlap(self):
+        return bool(self.sync) and collectives_active()
+
     def finish(self):
         """Issue all-reduces for buckets the hooks did not complete, then wait for everything."""
         if collectives_active() and self.sync:

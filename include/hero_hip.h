@@ -100,6 +100,22 @@ typedef struct HeroWgradProblem {
   int split_hint;
 } HeroWgradProblem;
 int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int dtype, hero_stream_t stream);
+/* Batched weight gradients, whole tiles: up to HERO_WGRAD_BATCH_MAX problems over the same K rows - the weight
+ * gradients of ALL BertLayers of an encoder, queued during the backward pass (model/layers.py:112-114, 173, 231, 245 x
+ * num_hidden_layers) - in ONE launch.  Whole 192 x 192 output tiles per workgroup in full rounds of the chip (plain
+ * fp32 read-add-write, no atomics), the remaining tiles cut into k-slices whose atomics are applied in slice order:
+ * dw is bit-reproducible for a fixed problem list.  Two steps:
+ *   hero_wgrad_batch_plan  (host, no device work): writes the schedule for (shapes of probs, K) into `plan`
+ *                          (int32 words, host memory); returns the number of words, 0 if the group is too small
+ *                          for this kernel (fewer tiles than workgroups: use hero_wgrad_group), < 0 on error /
+ *                          insufficient capacity.  Depends only on M, N of the problems and K: cache it.
+ *   hero_wgrad_batch       launches with the plan copied to device memory by the caller (plan_dev, plan_words).
+ * bf16 only; M, N multiples of 8; pointers 16-byte aligned; one launch at a time per device (the slice-order flags
+ * are library state). */
+#define HERO_WGRAD_BATCH_MAX 32
+int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K, int32_t* plan, int capacity_words);
+int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int dtype, const int32_t* plan_dev, int plan_words,
+                     hero_stream_t stream);
 int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
                                       * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
                                       * bits 8+: M-tiles per L2 locality group; -1 heuristic */

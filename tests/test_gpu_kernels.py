@@ -197,6 +197,86 @@ def test_wgrad_group_stream_k(HF, Lb, rows):
     torch.testing.assert_close(out2[1], dys[3].float().t() @ xs[3].float(), rtol=1e-4, atol=1e-3 * math.sqrt(rows))
 
 
+def _batch_problems(Lb, rows, layers, shapes, ragged_cols=False):
+    dtype = torch.bfloat16
+    dys, xs, outs = [], [], []
+    for l in range(layers):
+        for i, (n, k) in enumerate(shapes):
+            dys.append(rnd(rows, n, dtype=dtype, seed=100 + 10 * l + i))
+            xs.append(rnd(rows, k, dtype=dtype, seed=200 + 10 * l + i))
+            outs.append(torch.full((n, k), 0.25, device="cuda"))
+    n = len(dys)
+    probs = (Lb.WgradProblem * n)()
+    for i in range(n):
+        m_, k_ = outs[i].shape
+        probs[i] = Lb.WgradProblem(dys[i].data_ptr(), xs[i].data_ptr(), outs[i].data_ptr(), m_, k_, m_, k_, k_, 4)
+    return dys, xs, outs, probs
+
+
+def _run_batch(Lb, probs, n, rows):
+    import numpy as np
+    buf = np.zeros(8 + 8 * 256 * 16, dtype=np.int32)
+    words = Lb.lib().hero_wgrad_batch_plan(probs, n, rows, buf.ctypes.data, buf.size)
+    assert words > 8, words
+    plan = torch.from_numpy(buf[:words].copy()).cuda()
+    Lb.check(Lb.lib().hero_wgrad_batch(probs, n, rows, Lb.BF16, plan.data_ptr(), words, Lb.stream()))
+    torch.cuda.synchronize()
+    return buf[:words]
+
+
+@pytest.mark.parametrize("rows,layers", [(1920, 3), (1000, 6), (12000, 6)])
+def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
+    """hero_wgrad_batch: the weight gradients of ALL layers of an encoder over the same rows in one launch - whole
+    192 x 192 tiles in full rounds (plain fp32 read-add-write), the last partial round cut into k-slices with ordered
+    atomics.  (1920, 3) = the Temporal Transformer (576 tiles: 2 rounds + 64 tiles x 4 slices), (12000, 6) = the
+    cross-modal stack of the benched step (1152 tiles: 4 rounds + 128 tiles x 2 slices), 1000 rows: a reduction tail.
+    Accumulates into existing values; the result is BIT-REPRODUCIBLE run to run."""
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    dys, xs, outs, probs = _batch_problems(Lb, rows, layers, shapes)
+    n = len(dys)
+    plan = _run_batch(Lb, probs, n, rows)
+    assert plan[6] == layers * 192
+    if rows != 12000:
+        assert plan[7] > 1                      # the tail round is sliced
+    first = [o.clone() for o in outs]
+    for i in range(n):
+        ref = dys[i].float().t() @ xs[i].float() + 0.25
+        torch.testing.assert_close(outs[i], ref, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    for rep in range(2):
+        for o in outs:
+            o.fill_(0.25)
+        _run_batch(Lb, probs, n, rows)
+        for o, f in zip(outs, first):
+            assert torch.equal(o, f), "hero_wgrad_batch is not bit-reproducible"
+    # the slice-order flags are back to zero: a second launch right behind the first one accumulates once more
+    _run_batch(Lb, probs, n, rows)
+    for i in (0, n - 1):
+        ref = 2 * (dys[i].float().t() @ xs[i].float()) + 0.25
+        torch.testing.assert_close(outs[i], ref, rtol=1e-4, atol=2e-3 * math.sqrt(rows))
+
+
+def test_wgrad_batch_ragged_shapes_and_small_groups(HF, Lb):
+    """Output shapes that are not multiples of the 192 x 192 tile (4352-wide projections, a 1000 x 776 weight), a
+    column-sliced dY, and the plan refusing groups smaller than one round of the chip (-> hero_wgrad_group)."""
+    import numpy as np
+    rows = 1920
+    shapes = [(768, 4352), (1000, 776), (768, 4352), (2304, 768), (768, 3072), (3072, 768)]
+    dys, xs, outs, probs = _batch_problems(Lb, rows, 1, shapes)
+    wide = rnd(rows, 2304, dtype=torch.bfloat16, seed=77)
+    probs[3] = Lb.WgradProblem(wide.data_ptr() + 768 * 2, xs[3].data_ptr(), outs[3].data_ptr(), 768, 768, 2304, 768, 768, 4)
+    outs[3].fill_(0.25)
+    _run_batch(Lb, probs, len(shapes), rows)
+    for i in range(len(shapes)):
+        dy = wide[:, 768:1536] if i == 3 else dys[i]
+        ref = dy.float().t() @ xs[i].float() + 0.25
+        got = outs[i][:768] if i == 3 else outs[i]
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    assert float((outs[3][768:] - 0.25).abs().max()) == 0.0          # rows of dW outside the problem are untouched
+    buf = np.zeros(8 + 8 * 256 * 16, dtype=np.int32)
+    small = (Lb.WgradProblem * 2)(probs[4], probs[5])
+    assert Lb.lib().hero_wgrad_batch_plan(small, 2, rows, buf.ctypes.data, buf.size) == 0
+
+
 def test_deferred_weight_gradients_are_flushed_with_the_backward_pass(HF, Lb):
     """Sink-accumulated weight gradients are queued during backward and launched in groups; whoever looks at a
     .grad after backward() sees the complete sum, whatever the number of queued problems."""

@@ -280,6 +280,10 @@ def main():
                          "batch (SURVEY 8d), D3 = configs[3] multi-task pre-training, D4 = configs[4] 256-frame videos "
                          "with the batch sized to HBM")
     ap.add_argument("--videos", type=int, default=0, help="D4: videos per step (0 = fill ~80 %% of HBM)")
+    ap.add_argument("--feed", type=int, default=0,
+                    help="D2: rotate this many DISTINCT pinned host batches through hero_amd.loader.StaticBatchFeeder (H2D of "
+                         "the frame features on a copy stream one step ahead, index tensors rebuilt on the device) instead of "
+                         "re-running one HBM-resident batch; the headline value is the resident one (0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -317,8 +321,24 @@ def main():
     model = build_model(device, cfg_path)
     trainer = TrainStep(model, use_graph=(not dist_on and not args.no_graph),
                         static_usage=True)     # drop_svmr_prob = 0: every step uses the same parameters
-    batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device)
+    feeder, host_batches = None, []
+    if args.feed > 0:
+        from hero_amd.loader import StaticBatchFeeder, pin_batch
+        host_batches = [pin_batch(make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank + 100 * i)) for i in range(args.feed)]
+        feeder = StaticBatchFeeder(host_batches[0], device)
+        batch = feeder.static
+    else:
+        batch = make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank, device=device)
     sh = SHAPES["D2"]
+    fed = [0]
+
+    def step():
+        if feeder is None:
+            return trainer.micro_step(batch)
+        b = feeder.commit()                                              # the batch prefetched during the previous step
+        fed[0] += 1
+        feeder.prefetch(host_batches[fed[0] % len(host_batches)])        # next one: copy stream, overlaps this step
+        return trainer.micro_step(b)
 
     def sync():
         torch.cuda.synchronize()
@@ -327,12 +347,15 @@ def main():
             torch.cuda.synchronize()
 
     trainer.prepare(batch)                           # hipGraph capture is setup, never inside the timed region
+    if feeder is not None:
+        feeder.capture()
+        feeder.prefetch(host_batches[0])
     for _ in range(args.warmup):
-        trainer.micro_step(batch)
+        step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.micro_step(batch)
+        loss = step()
     sync()
     dt = time.perf_counter() - t0
     if dist_on:
@@ -400,7 +423,10 @@ def main():
                                    "32 videos x 60 frames, 15 subs x (4 frames + 20 tokens), 15-token query; "
                                    "vfeat 4352; fwd + VSM loss + bwd, all-reduce/clip/AdamW every 2nd micro-step)",
                        "global_batch": sh["videos"] * world, "parallelism": "dp%d" % world,
-                       "dropout": 0.1, "grad_accum": 2, "launch": launch_mode},
+                       "dropout": 0.1, "grad_accum": 2, "launch": launch_mode,
+                       "input": ("%d distinct pinned host batches rotated through StaticBatchFeeder (33 MB of frame features per "
+                                 "micro-step over PCIe on a copy stream, one step ahead; index tensors rebuilt on the device)" % args.feed)
+                       if args.feed else "one batch resident in HBM"},
             "step_tflops": round(vps * fl_video / 1e12, 1),
             "step_frac_of_bf16_peak": round(vps * fl_video / 1e12 / world / BF16_PEAK_TFLOPS, 4),
             "final_loss": loss_val,

@@ -24,7 +24,7 @@ EXPORTS = [
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
     "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
     "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
-    "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats",
+    "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats", "hero_derive_multi",
 ]
 
 
@@ -43,6 +43,14 @@ class CrossEntropy(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("labels", C.c_void_p), ("loss", C.c_void_p), ("lse", C.c_void_p),
                 ("dloss", C.c_void_p), ("dlogits", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
                 ("ld", C.c_int), ("dtype", C.c_int), ("inv_temp", C.c_float), ("ignore_index", C.c_int64)]
+
+
+class Derive(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("mode", C.c_int), ("p0", C.c_int),
+                ("p1", C.c_int), ("p2", C.c_int)]
+
+
+DERIVE_MASK_ADD, DERIVE_F32, DERIVE_I32, DERIVE_FLAT_GATHER = 0, 1, 2, 3
 
 
 class WgradProblem(C.Structure):
@@ -197,6 +205,7 @@ def lib():
             getattr(L, fn).argtypes = [C.POINTER(st), C.c_void_p]
         L.hero_collate_subs.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
         L.hero_collate_gather_feats.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
+        L.hero_derive_multi.argtypes = [C.POINTER(Derive), C.c_int, C.c_void_p]
         L.hero_collate_clip_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hero_collate_frame_map.argtypes = [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]
         L.hero_cross_entropy_fwd.argtypes = [C.POINTER(CrossEntropy), C.c_void_p]

@@ -210,15 +210,20 @@ class DeviceCollate:
     def frame_map(self):
         return self.offsets, self.entries, self.inverse
 
-    def update(self, lengths, c_v_feats=None):
-        """lengths: dict of int32 arrays / tensors (video_collate's batch["lengths"] / lengths_from_lists).  Copies
-        them to the device (a few hundred bytes) and rebuilds every index tensor in place, stream-ordered, no
-        synchronisation.  c_v_feats (device, [B, NF, vfeat_dim] fp32): also rebuild f_v_feats from it."""
+    def load_lengths(self, lengths, src_device=None):
+        """Copy the length arrays into the device-side input slots (a few hundred bytes, stream-ordered).
+        lengths: host arrays (video_collate's batch["lengths"]) or, with src_device=True, a dict of int32 DEVICE
+        tensors of exactly the slot sizes (a staging copy made on another stream: StaticBatchFeeder)."""
         for k, dst in self._in.items():
-            src = torch.as_tensor(lengths[k], dtype=torch.int32)
+            src = lengths[k] if src_device else torch.as_tensor(lengths[k], dtype=torch.int32)
             if src.numel() > dst.numel() or (k in ("sub_nfrm", "sub_ntok", "vid_nfrm") and src.numel() != dst.numel()):
                 raise ValueError("DeviceCollate: %s has %d entries, the buffers were sized for %d" % (k, src.numel(), dst.numel()))
             dst[:src.numel()].copy_(src, non_blocking=True)
+        return self
+
+    def rebuild(self, c_v_feats=None):
+        """Rebuild every index tensor in place from the loaded lengths: kernels only, no host data, no synchronisation
+        (capturable in a hipGraph).  c_v_feats (device, [B, NF, vfeat_dim] fp32): also rebuild f_v_feats from it."""
         i, s, lib = self._in, L.stream(), L.lib()
         L.check(lib.hero_collate_subs(L.ptr(i["sub_nfrm"]), L.ptr(i["sub_ntok"]), L.ptr(self.f_gather_index),
                                       L.ptr(self.f_attn_masks), self.T, self.max_vl, self.Lf, s))
@@ -228,19 +233,23 @@ class DeviceCollate:
             L.check(lib.hero_collate_gather_feats(L.ptr(c_v_feats.contiguous()), L.ptr(self.f_v_feats), L.ptr(i["vid_sub_off"]),
                                                   L.ptr(i["vid_nfrm"]), L.ptr(i["sub_frm_off"]), L.ptr(i["sub_frm"]),
                                                   L.ptr(self._row_vid), self.T, self.max_vl, self.B, self.NF, self.f_v_feats.shape[2], s))
-            torch._C._increment_version(self.f_v_feats)
+            torch._C._increment_version([self.f_v_feats])
         L.check(lib.hero_collate_clip_mask(L.ptr(i["vid_nfrm"]), L.ptr(self.c_attn_masks), self.B, self.NF, s))
         L.check(lib.hero_collate_frame_map(L.ptr(i["vid_sub_off"]), L.ptr(i["sub_frm_off"]), L.ptr(i["sub_frm"]), None,
                                            L.ptr(self._counts), None, None, self.B, self.NF, self.Lf, 0, s))
-        self.offsets[0] = 0
+        self.offsets[:1].zero_()
         torch.cumsum(self._counts, 0, out=self.offsets[1:])          # exclusive scan of the counts (device op)
         self.inverse.fill_(-1)
         L.check(lib.hero_collate_frame_map(L.ptr(i["vid_sub_off"]), L.ptr(i["sub_frm_off"]), L.ptr(i["sub_frm"]),
                                            L.ptr(self.offsets), None, L.ptr(self.entries), L.ptr(self.inverse),
                                            self.B, self.NF, self.Lf, 1, s))
-        for t in (self.f_gather_index, self.f_attn_masks, self.c_attn_masks):
-            torch._C._increment_version(t)     # raw kernels wrote them: caches keyed on (address, version) must miss
+        # raw kernels wrote them: caches keyed on (address, version) must miss (the call takes an ITERABLE of tensors)
+        torch._C._increment_version([self.f_gather_index, self.f_attn_masks, self.c_attn_masks])
         return self
+
+    def update(self, lengths, c_v_feats=None):
+        """load_lengths + rebuild: lengths are host arrays (video_collate's batch["lengths"] / lengths_from_lists)."""
+        return self.load_lengths(lengths).rebuild(c_v_feats)
 
     def batch_entries(self):
         """The keys of the reference batch dict this object owns (+ `frame_map`, which replaces the host

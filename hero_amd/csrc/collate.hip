@@ -68,6 +68,25 @@ __global__ void row_video_kernel(const int32_t* __restrict__ vid_sub_off, int32_
 
 // one thread per output frame (video b, frame f): walk the video's subtitles in row order, their frame lists in slot
 // order - the order of the host builder's stable sort - and count (FILL = false) or record (FILL = true) the matches
+// Tensors DERIVED from the int64 index / mask tensors of a batch (additive attention masks, fp32 masks, int32 row
+// indices, the flat form of f_gather_index), all of a batch in ONE launch: blockIdx.y = descriptor.
+struct DeriveArgs { HeroDerive d[HERO_DERIVE_MAX]; };
+__global__ void derive_multi_kernel(DeriveArgs a) {
+  const HeroDerive d = a.d[blockIdx.y];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t x = d.src[i];
+    switch (d.mode) {
+      case HERO_DERIVE_MASK_ADD: static_cast<float*>(d.dst)[i] = (1.0f - (float)x) * -10000.0f; break;      // model/layers.py:299-302
+      case HERO_DERIVE_F32: static_cast<float*>(d.dst)[i] = (float)x; break;
+      case HERO_DERIVE_I32: static_cast<int32_t*>(d.dst)[i] = (int32_t)x; break;
+      default: {                                                     // HERO_DERIVE_FLAT_GATHER: p0 = row width, p1 = max_vl, p2 = max_sl
+        const int64_t row = i / d.p0;
+        static_cast<int32_t*>(d.dst)[i] = (int32_t)(x < d.p1 ? row * d.p1 + x : -(row * d.p2 + (x - d.p1)) - 2);
+      }
+    }
+  }
+}
+
 template <bool FILL>
 __global__ void frame_map_kernel(const int32_t* __restrict__ vid_sub_off, const int32_t* __restrict__ sub_frm_off,
                                  const int32_t* __restrict__ sub_frm, const int32_t* __restrict__ offsets, int32_t* __restrict__ counts,
@@ -119,6 +138,23 @@ extern "C" int hero_collate_gather_feats(const float* c_v_feats, float* f_v_feat
   hipLaunchKernelGGL(gather_feats_kernel, dim3(T * max_vl), dim3(256), 0, s, reinterpret_cast<const float4*>(c_v_feats),
                      reinterpret_cast<float4*>(f_v_feats), row_vid, vid_nfrm, sub_frm_off, sub_frm, max_vl, NF, D / 4);
   return check_launch("hero_collate_gather_feats");
+}
+
+extern "C" int hero_derive_multi(const HeroDerive* d, int n, hero_stream_t stream) {
+  HERO_REQUIRE(d && n >= 1 && n <= HERO_DERIVE_MAX, "hero_derive_multi: 1..%d descriptors", HERO_DERIVE_MAX);
+  DeriveArgs a;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    HERO_REQUIRE(d[i].src && d[i].dst && d[i].n >= 0 && d[i].mode >= HERO_DERIVE_MASK_ADD && d[i].mode <= HERO_DERIVE_FLAT_GATHER,
+                 "hero_derive_multi: bad descriptor %d", i);
+    HERO_REQUIRE(d[i].mode != HERO_DERIVE_FLAT_GATHER || (d[i].p0 > 0 && d[i].p1 > 0 && d[i].p2 > 0), "hero_derive_multi: flat gather needs widths");
+    a.d[i] = d[i];
+    most = d[i].n > most ? d[i].n : most;
+  }
+  if (most == 0) return HERO_OK;
+  const int gx = (int)((most + 255) / 256 < 1024 ? (most + 255) / 256 : 1024);
+  hipLaunchKernelGGL(derive_multi_kernel, dim3(gx, n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("hero_derive_multi");
 }
 
 extern "C" int hero_collate_clip_mask(const int32_t* vid_nfrm, int64_t* attn_mask, int B, int NF, hero_stream_t stream) {

@@ -1356,9 +1356,9 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
   using namespace hero::ws;
   typedef Geo<3, 3> G;
   HERO_REQUIRE(probs && n >= 1 && n <= HERO_WGRAD_BATCH_MAX, "hero_wgrad_batch_plan: 1..%d problems", HERO_WGRAD_BATCH_MAX);
-  HERO_REQUIRE(K >= 64, "hero_wgrad_batch_plan: K = %d", K);
+  HERO_REQUIRE(K >= 1, "hero_wgrad_batch_plan: K = %d", K);
   const int nwg = num_cus(), ksteps = (K + 63) / 64;
-  if (nwg % 8 != 0) return 0;
+  if (nwg % 8 != 0 || ksteps < 8) return 0;            // short reductions: the per-group path (hero_wgrad_group / hero_gemm)
   // tiles in patch order: up to 8 x 4 (or tiles_m x 32 / tiles_m) tiles of one problem are consecutive = one XCD's round
   struct T3 { int prob, mt, nt; };
   std::vector<T3> tiles;

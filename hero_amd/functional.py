@@ -589,11 +589,13 @@ def _as2d(x):
 _MEMO = {}
 
 
-def memo(tag, tensors, fn, extra=()):
+def memo(tag, tensors, fn, extra=(), spec=None):
     """Cache a tensor DERIVED from batch index / mask tensors (int32 row indices, additive masks,
     flat gather maps) on the identity + version of its sources: the same batch object is fed for
     several micro-steps (gradient accumulation, hipGraph warm-up) and these conversions are a few
-    dozen tiny launches each time.  The sources are kept alive so their addresses stay unique."""
+    dozen tiny launches each time.  The sources are kept alive so their addresses stay unique.
+    spec = (L.DERIVE_* mode, p0, p1, p2): the entry is an elementwise function of ONE contiguous int64 source that
+    hero_derive_multi computes - refresh_memo then redoes all such entries in one launch."""
     key = (tag, extra) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
     hit = _MEMO.get(key)
     if hit is not None:
@@ -601,21 +603,35 @@ def memo(tag, tensors, fn, extra=()):
     if len(_MEMO) > 512:
         _MEMO.clear()
     out = fn()
-    _MEMO[key] = (out, tensors, fn)
+    if spec is not None and not (len(tensors) == 1 and tensors[0].dtype == torch.int64 and tensors[0].is_contiguous()
+                                 and tensors[0].is_cuda and out.is_contiguous() and out.numel() == tensors[0].numel()):
+        spec = None
+    _MEMO[key] = (out, tensors, fn, spec)
     return out
 
 
-def refresh_memo():
-    """Recompute every memoised derived tensor IN PLACE from the current contents of its sources.  For callers
-    that rewrite batch buffers in place (hero_amd.collate.DeviceCollate, or new data copied into a captured
-    batch): captured graphs and cached maps hold the derived tensors by address."""
-    for out, _, fn in list(_MEMO.values()):
+def refresh_memo(sources=None):
+    """Recompute memoised derived tensors IN PLACE from the current contents of their sources.  For callers that
+    rewrite batch buffers in place (hero_amd.collate.DeviceCollate, or new data copied into a captured batch):
+    captured graphs and cached maps hold the derived tensors by address.  sources: only the entries derived from one
+    of these tensors (default: every entry).  Entries with a `spec` go out together as hero_derive_multi launches."""
+    ptrs = None if sources is None else {t.data_ptr() for t in sources}
+    batch = []
+    for out, srcs, fn, spec in list(_MEMO.values()):
+        if ptrs is not None and not any(t.data_ptr() in ptrs for t in srcs):
+            continue
+        if spec is not None:
+            batch.append(L.Derive(L.ptr(srcs[0]), L.ptr(out), out.numel(), spec[0], spec[1], spec[2], spec[3]))
+            continue
         new = fn()
         if isinstance(out, torch.Tensor):
             if new.shape != out.shape:
                 raise RuntimeError("refresh_memo: a derived tensor changed shape %s -> %s; the batch structure is "
                                    "different, not just its contents" % (tuple(out.shape), tuple(new.shape)))
             out.copy_(new)
+    for i in range(0, len(batch), 16):
+        part = batch[i:i + 16]
+        L.check(L.lib().hero_derive_multi((L.Derive * len(part))(*part), len(part), L.stream()))
 
 
 def as_mask_add(mask, S, Lq):
@@ -630,7 +646,7 @@ def as_mask_add(mask, S, Lq):
     if mask.requires_grad:
         return ((1.0 - mask.reshape(S, Lq).to(torch.float32)) * -10000.0).contiguous()
     return memo("mask_add", (mask,), lambda: ((1.0 - mask.reshape(S, Lq).to(torch.float32)) * -10000.0).contiguous(),
-                (S, Lq))
+                (S, Lq), spec=(L.DERIVE_MASK_ADD, 0, 0, 0))
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -16,7 +16,7 @@ def _f32c(t):
     if t.dtype == torch.float32 and t.is_contiguous():
         return t.detach()
     if not t.is_floating_point():                       # 0/1 masks: converted once per batch object
-        return HF.memo("mask_f32c", (t,), lambda: t.to(torch.float32).contiguous())
+        return HF.memo("mask_f32c", (t,), lambda: t.to(torch.float32).contiguous(), spec=(L.DERIVE_F32, 0, 0, 0))
     return t.detach().to(torch.float32).contiguous()
 
 

@@ -3,6 +3,7 @@ HIP kernel per embedding (hero_layernorm_fwd with gathered tables)."""
 import torch
 from torch import nn
 
+from .. import _lib as L
 from .. import functional as HF
 from .layers import LayerNorm, _drop
 
@@ -23,7 +24,8 @@ def _row_index(ids, rows, cols_per_row):
     if ids.shape != (rows, cols_per_row):
         raise ValueError("index tensor of shape %s does not match (%d, %d)" %
                          (tuple(ids.shape), rows, cols_per_row))
-    out = HF.memo("row_index", (ids,), lambda: ids.reshape(-1).to(torch.int32).contiguous(), (rows, cols_per_row))
+    out = HF.memo("row_index", (ids,), lambda: ids.reshape(-1).to(torch.int32).contiguous(), (rows, cols_per_row),
+                  spec=(L.DERIVE_I32, 0, 0, 0))
     out._hero_period = period
     return out
 
@@ -110,6 +112,9 @@ class FrameEmbeddings(nn.Module):
     def forward(self, frame_feat, position_ids=None):
         B, Lc, D = frame_feat.shape
         if position_ids is None:
+            if Lc > self.position_embeddings.num_embeddings:       # nn.Embedding raises here; a raw kernel would read past the table
+                raise IndexError("FrameEmbeddings: %d frames, the position table has %d rows (max_position_embeddings)"
+                                 % (Lc, self.position_embeddings.num_embeddings))
             key = (B, Lc, str(frame_feat.device))
             pid = _ARANGE.get(key)
             if pid is None:

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import _lib as L
 from .. import functional as HF
 from .embed import FrameEmbeddings, ImageEmbeddings, QueryFeatEmbeddings, SubEmbeddings
 from .layers import (BertAttention, BertEncoder, BertLMPredictionHead, BertPooler, LayerNorm,
@@ -136,7 +137,8 @@ class CrossModalTrm(RobertaPreTrainedModel):
             g = gather_index.to(torch.int64)
             flat = torch.where(g < max_vl, row * max_vl + g, -(row * max_sl + (g - max_vl)) - 2)
             return flat.reshape(-1).to(torch.int32).contiguous()
-        return HF.memo("flat_gather", (gather_index,), build, (max_vl, max_sl))
+        return HF.memo("flat_gather", (gather_index,), build, (max_vl, max_sl),
+                       spec=(L.DERIVE_FLAT_GATHER, gather_index.shape[1], max_vl, max_sl))
 
     def _compute_img_txt_embeddings(self, input_ids, position_ids, img_feat, img_pos_ids,
                                     gather_index, txt_type_ids=None, img_type_ids=None,
@@ -251,7 +253,7 @@ class QueryFeatEncoder(nn.Module):
 
     def forward(self, query_feat, query_attn_mask, query_pos_ids=None):
         h = self.query_pos_embed(self.query_input_proj(query_feat), query_pos_ids)
-        m = HF.memo("mask_f32", (query_attn_mask,), lambda: query_attn_mask.to(torch.float32))
+        m = HF.memo("mask_f32", (query_attn_mask,), lambda: query_attn_mask.to(torch.float32), spec=(L.DERIVE_F32, 0, 0, 0))
         ext = HF.as_mask_add(query_attn_mask, m.shape[0], m.shape[1])[:, None, None, :]
         attended = self.query_self_attention(h, ext)[0]
         if self.modularized and self.fused_pool:

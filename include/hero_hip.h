@@ -467,6 +467,20 @@ int hero_collate_frame_map(const int32_t* vid_sub_off, const int32_t* sub_frm_of
                            int32_t* counts, int32_t* entries, int32_t* inverse, int B, int NF, int Lf, int fill,
                            hero_stream_t stream);
 
+/* Everything the model derives from the int64 index / mask tensors of a batch, in one launch: additive attention   */
+/* masks (1 - m) * -10000 (model/layers.py:299-302), fp32 masks, int32 row indices, and f_gather_index as flat rows   */
+/* of hero_gather_rows (>= 0: image row, <= -2: text row; model/encoder.py:271-279).  src int64, n elements.          */
+enum { HERO_DERIVE_MASK_ADD = 0, HERO_DERIVE_F32 = 1, HERO_DERIVE_I32 = 2, HERO_DERIVE_FLAT_GATHER = 3 };
+#define HERO_DERIVE_MAX 16
+typedef struct HeroDerive {
+  const int64_t* src;
+  void* dst;        /* fp32 (MASK_ADD, F32) or int32 (I32, FLAT_GATHER), n elements */
+  int64_t n;
+  int mode;
+  int p0, p1, p2;   /* FLAT_GATHER: row width of src, max_vl, max_sl */
+} HeroDerive;
+int hero_derive_multi(const HeroDerive* d, int n, hero_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

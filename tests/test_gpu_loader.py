@@ -1,0 +1,115 @@
+"""Loader half of SURVEY 8(f) N4: the reference's PrefetchLoader protocol (data/loader.py:89-144) and the static-buffer
+feeder that lets a hipGraph-captured step consume a stream of DIFFERENT host batches."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(n, seed0=10):
+    """same padded shapes (8 subtitles x <= 4 frames, <= 8 tokens, <= 32 frames), different contents / lengths"""
+    from hero_amd import synth
+    out = []
+    for s in range(n):
+        gen = torch.Generator().manual_seed(seed0 + s)
+        ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))     # noqa: E731
+        subs, n_frames = [], []
+        for v in range(2):
+            nf, cur, f0 = (32 if v == 0 else ri(20, 31)), [], 0
+            for s_ in range(8):
+                k = 4 if s_ == 0 else ri(0, 4)
+                fr = list(range(f0, min(f0 + k, nf)))
+                f0 += len(fr)
+                cur.append((fr, 8 if s_ == 0 else ri(2, 8)))
+            subs.append(cur)
+            n_frames.append(nf)
+        b = synth.video_batch(subs, n_frames, 96, 160, gen, max_frames=32)
+        b.update(synth.query_batch(2, [12, ri(4, 11)], 160, gen))
+        b["targets"] = torch.tensor([[1, 3], [2, ri(3, 9)]])
+        b["q_vidx"] = torch.arange(2)
+        out.append(b)
+    return out
+
+
+def test_prefetch_loader_follows_the_reference_protocol():
+    from hero_amd.loader import PrefetchLoader
+    host = _batches(3)
+    got = list(PrefetchLoader(host, "cuda"))
+    assert len(got) == 3
+    for h, d in zip(host, got):
+        for k, v in h.items():
+            if torch.is_tensor(v):
+                assert d[k].is_cuda and torch.equal(d[k].cpu(), v), k
+            elif k != "lengths":
+                assert d[k] == v                     # host lists pass through untouched
+    assert len(PrefetchLoader(host, "cuda")) == 3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_static_feeder_feeds_a_stream_of_batches(use_graph):
+    """A (captured) training step fed by StaticBatchFeeder with rotating, different batches gives the losses of an
+    eager run that moves every batch to the device the plain way."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.loader import StaticBatchFeeder, pin_batch
+    from hero_amd.model.layers import BertEncoder
+    from hero_amd.step import TrainStep
+    from hero_amd.utils.misc import set_dropout
+    from tests.util import load_tiny, to_dev
+    hero_amd.set_compute_dtype(torch.float32)
+    host = _batches(4)
+    assert all(h["f_attn_masks"].shape == host[0]["f_attn_masks"].shape for h in host)
+    order = [0, 1, 2, 3, 1, 0]
+
+    def fresh():
+        HF.set_grad_sink(None)
+        HF.clear_weight_cache()
+        model, _, _ = load_tiny("cuda")
+        model.train()
+        set_dropout(model, 0.0)
+        return model
+
+    BertEncoder.allow_packing = False
+    try:
+        opts = dict(learning_rate=1e-3, warmup_steps=2, num_train_steps=100)
+        ts = TrainStep(fresh(), opts=opts)
+        d0 = to_dev(host[0], "cuda")
+        for _ in range(4):                           # what graph capture runs as warm-up on its first batch
+            ts.micro_step(d0)
+        want = [float(ts.micro_step(to_dev(host[i], "cuda"))) for i in order]
+        HF.set_grad_sink(None)
+
+        ts = TrainStep(fresh(), opts=opts, use_graph=use_graph)
+        feeder = StaticBatchFeeder(pin_batch(host[0]), "cuda")
+        if use_graph:
+            ts.prepare(feeder.static)                # 4 eager warm-up micro-steps + capture on host[0]
+        else:
+            for _ in range(4):
+                ts.micro_step(feeder.static)
+        feeder.capture()
+        pinned = [pin_batch(h) for h in host]
+        feeder.prefetch(pinned[order[0]])
+        got = []
+        for n, i in enumerate(order):
+            b = feeder.commit()
+            if n + 1 < len(order):
+                feeder.prefetch(pinned[order[n + 1]])
+            got.append(float(ts.micro_step(b)))
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-5)
+        assert torch.equal(feeder.static["f_attn_masks"].cpu(), host[order[-1]]["f_attn_masks"])
+        assert torch.equal(feeder.static["f_v_feats"].cpu(), host[order[-1]]["f_v_feats"])
+    finally:
+        BertEncoder.allow_packing = True
+        HF.set_grad_sink(None)
+        hero_amd.set_compute_dtype(torch.bfloat16)
+
+
+def test_feeder_rejects_other_shapes():
+    from hero_amd.loader import StaticBatchFeeder, pin_batch
+    from hero_amd.synth import make_batch
+    a = make_batch("D1", vfeat_dim=96, vocab=160, seed=1)
+    b = make_batch("D1", vfeat_dim=96, vocab=160, seed=1, videos=3)
+    f = StaticBatchFeeder(pin_batch(a), "cuda", capture_commit=False)
+    with pytest.raises(ValueError):
+        f.prefetch(pin_batch(b))

@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "product"
 quick = tag != "product"
 
 
-def run(rows, shapes, label):
+def run(rows, shapes, label, same_tile=False):
     dys = [torch.randn(rows, n, device="cuda").to(dt) for n, _ in shapes]
     xs = [torch.randn(rows, k, device="cuda").to(dt) for _, k in shapes]
     outs = [torch.zeros(n, k, device="cuda") for n, k in shapes]
@@ -23,6 +23,9 @@ def run(rows, shapes, label):
                                                outs[i].shape[0], outs[i].shape[1], outs[i].shape[1], 4) for i in range(n)])
     buf = np.zeros(8 + 8 * 256 * 16, dtype=np.int32)
     words = L.lib().hero_wgrad_batch_plan(pr, n, rows, buf.ctypes.data, buf.size)
+    if same_tile:             # every workgroup on the SAME tile (all operand reads hit the L2): timing only, use a noepi build
+        it = buf[8:words].reshape(-1, 8)
+        it[:, 0], it[:, 1], it[:, 2] = 0, 0, 0
     plan = torch.from_numpy(buf[:words].copy()).cuda()
     fn = lambda: L.check(L.lib().hero_wgrad_batch(pr, n, rows, L.BF16, plan.data_ptr(), words, L.stream()))
     fn(); torch.cuda.synchronize()
@@ -35,6 +38,8 @@ def run(rows, shapes, label):
 
 for rows in ((12032,) if quick else (3008, 6016, 12032)):
     run(rows, LAYER * 4, "4 layers (3 full rounds)")
+if "noepi" in tag or "nomfma" in tag:
+    run(12032, LAYER * 4, "4 layers, every WG the same tile", same_tile=True)
 if not quick:
     run(12000, LAYER * 6, "6 layers (benched step)")
     run(1920, LAYER * 3, "3 layers (Temporal Transformer)")

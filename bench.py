@@ -319,8 +319,12 @@ def main():
     with open(cfg_path, "w") as f:
         json.dump(HERO_BASE, f)
     model = build_model(device, cfg_path)
-    trainer = TrainStep(model, use_graph=(not dist_on and not args.no_graph),
-                        static_usage=True)     # drop_svmr_prob = 0: every step uses the same parameters
+    # drop_svmr_prob = 0: every step uses the same parameters; every rank's batch has the same shape.
+    # N = 1: the step is captured in hipGraphs and replayed.  N > 1: the eager run (RCCL all-reduces issued from the
+    # backward hooks) is timed FIRST - it is the mode every multi-rank test covers - and then, unless HERO_DP_GRAPH=0,
+    # the step is captured WITH its collectives and timed again under a watchdog; the line reports the faster of the
+    # two measured runs and says which (`config.launch`).  Each run is exactly --steps micro-steps between barriers.
+    trainer = TrainStep(model, use_graph=(not dist_on and not args.no_graph), static_usage=True, uniform_shapes=True)
     feeder, host_batches = None, []
     if args.feed > 0:
         from hero_amd.loader import StaticBatchFeeder, pin_batch
@@ -346,23 +350,30 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    trainer.prepare(batch)                           # hipGraph capture is setup, never inside the timed region
-    if feeder is not None:
-        feeder.capture()
-        feeder.prefetch(host_batches[0])
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    loss_val = float(loss)
+    def timed_run():
+        trainer.prepare(batch)                       # hipGraph capture is setup, never inside the timed region
+        if feeder is not None:
+            feeder.capture()
+            if not feeder._ready:
+                feeder.prefetch(host_batches[0])
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss_ = step()
+        sync()
+        dt_ = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt_], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, float(loss_)
+
+    dt, loss_val = timed_run()
+    graph_mode = trainer.use_graph
+    try_graph = dist_on and not args.no_graph and os.environ.get("HERO_DP_GRAPH", "1") not in ("", "0")
+    eager_ms = dt / args.steps * 1e3
 
     # ---- roofline leg: HIP events around every GEMM launch over extra, identical steps ----------
     roof = None
@@ -404,19 +415,17 @@ def main():
     elif world > 1:
         for _ in range(args.profile_steps):
             trainer.micro_step(batch)
-    launch_mode = "hipGraph replay" if (not dist_on and not args.no_graph) else "eager"
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, HERO_BASE)
 
-    if rank == 0:
-        vps = sh["videos"] * world * args.steps / dt
+    def line(dt_, loss_, launch_mode):
+        vps = sh["videos"] * world * args.steps / dt_
         fl_video = algorithmic_flops_per_video(sh)
-        out = {
+        return {
             "metric": "videos/sec training step, HERO-base TVR-shaped batch",
             "value": round(vps, 2), "unit": "videos/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "warmup": args.warmup, "ms_per_step": round(dt_ / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: HERO-base TVR finetune micro-step (train-tvr-8gpu.json shapes: "
@@ -429,14 +438,48 @@ def main():
                        if args.feed else "one batch resident in HBM"},
             "step_tflops": round(vps * fl_video / 1e12, 1),
             "step_frac_of_bf16_peak": round(vps * fl_video / 1e12 / world / BF16_PEAK_TFLOPS, 4),
-            "final_loss": loss_val,
+            "final_loss": loss_,
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+
+    out = line(dt, loss_val, "hipGraph replay" if graph_mode else "eager")
+    hard_exit = False
+    if try_graph:
+        # Second measured run of the same K steps: the step captured WITH its RCCL collectives.  A watchdog prints the
+        # eager line and leaves if the captured run does not come back (a wedged collective cannot be recovered from
+        # inside the process); whichever run was faster is reported, the other one's time goes into `config`.
+        import threading
+        finished = threading.Event()
+
+        def bail():
+            if not finished.is_set():
+                if rank == 0:
+                    out["config"]["launch"] += " (the hipGraph run with captured RCCL collectives timed out)"
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        timer = threading.Timer(float(os.environ.get("HERO_DP_GRAPH_TIMEOUT", "240")), bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            trainer.enable_graph(collectives=True)
+            dt_g, loss_g = timed_run()
+            if dt_g < dt and loss_g == loss_g:
+                out = line(dt_g, loss_g, "hipGraph replay (step captured with its RCCL collectives)")
+                out["config"]["eager_ms_per_step"] = round(eager_ms, 3)
+            else:
+                out["config"]["graph_ms_per_step"] = round(dt_g / args.steps * 1e3, 3)
+        except Exception as e:                       # noqa: BLE001 - any capture failure: the eager measurement stands
+            out["config"]["launch"] += " (hipGraph capture with RCCL collectives failed: %s)" % type(e).__name__
+            hard_exit = True                         # the process group may be unusable: no orderly teardown
+        finished.set()
+        timer.cancel()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if hard_exit:
+        os._exit(0)
     if dist_on:
         torch.distributed.destroy_process_group()
-
 
 if __name__ == "__main__":
     main()

@@ -11,6 +11,7 @@ backward is still running, clipping + averaging + AdamW are one kernel pass, and
 shapes on one GPU — the whole micro-step (forward, loss, backward, optimiser) is captured once in
 a hipGraph and replayed, which removes the ~900 host-side launches per step.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -39,13 +40,18 @@ def qkv_groups(model):
 
 class TrainStep:
     def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=False,
-                 grad_compress="bf16"):
+                 grad_compress="bf16", uniform_shapes=False, graph_collectives=None):
         """static_usage: the set of parameters that receive gradients only grows over the run (single-task
         fine-tuning with drop_svmr_prob = 0, as bench.py runs it) - lets the gradient buckets that also
         hold never-used parameters overlap with backward too.  Off by default: the reference configs
         drop the st/ed head on 80 % of the steps (config/train-tvr-8gpu.json:30).
         grad_compress: 'bf16' (default) sends the gradient buckets as bf16 - the reference's payload is fp16
-        (train-tvr-8gpu.json:67 "fp16": true) - None keeps fp32 on the wire."""
+        (train-tvr-8gpu.json:67 "fp16": true) - None keeps fp32 on the wire.
+        uniform_shapes: every rank feeds batches of the same padded shape - the cross-rank negatives skip their
+        per-forward host-side size exchange (utils/distributed.gather_negatives).
+        graph_collectives: with use_graph in a data-parallel run, capture the step INCLUDING the bucketed RCCL
+        all-reduces and the forward all-gathers (they are issued on streams that join the capture); default: the
+        HERO_DP_GRAPH environment switch, off - N > 1 then runs eagerly, the mode every multi-rank test covers."""
         self.model = model
         self.opts = SimpleNamespace(**{**TVR_OPTS, **(opts or {})})
         self.task = task
@@ -56,7 +62,10 @@ class TrainStep:
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152
-        self.use_graph = use_graph and not D.collectives_active()
+        D.UNIFORM_SHAPES[0] = bool(uniform_shapes)
+        if graph_collectives is None:
+            graph_collectives = os.environ.get("HERO_DP_GRAPH", "0") not in ("", "0")
+        self.use_graph = use_graph and (not D.collectives_active() or (graph_collectives and uniform_shapes))
         self._graphs = {}             # task -> (plain graph, its loss, boundary graph, its loss, static batch)
         self._window = []             # tasks of the micro-steps accumulated since the last optimiser step
         # compute copies of the weights are cached per optimiser step: anything else that rewrites parameters
@@ -65,6 +74,15 @@ class TrainStep:
         dev = next(model.parameters()).device
         self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side optimiser step
         self._lr_t = torch.zeros(8, dtype=torch.float32, device=dev)
+
+    def enable_graph(self, collectives=False):
+        """Switch an eager trainer to hipGraph replay (the next micro_step / prepare captures).  collectives: allow
+        it in a data-parallel run - needs uniform_shapes (see __init__)."""
+        if D.collectives_active() and not (collectives and D.UNIFORM_SHAPES[0]):
+            raise RuntimeError("graph replay of a data-parallel step needs collectives=True and uniform_shapes=True")
+        if self.micro % self.opts.gradient_accumulation_steps != 0:
+            raise RuntimeError("switch to graph replay on an accumulation boundary")
+        self.use_graph = True
 
     # ---- pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch, task=None):
@@ -140,9 +158,14 @@ class TrainStep:
         torch.cuda.synchronize()
         self.micro += 2 * accum
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        # with a process group alive its watchdog thread queries events of earlier collectives: only THIS thread's
+        # calls may invalidate the capture
+        mode = dict(capture_error_mode="thread_local") if D.collectives_active() else {}
+        self.arena.set_sync(False)                   # accumulation micro-step: no collective in this graph
+        with torch.cuda.graph(ga, **mode):
             loss_a = self._fwd_bwd(batch, task)
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        self.arena.set_sync(True)                    # boundary: bucket all-reduces (RCCL's stream joins the capture)
+        with torch.cuda.graph(gb, pool=ga.pool(), **mode):
             loss_b = self._fwd_bwd(batch, task)
             self._optimise(device_state=True)
         self._graphs[task] = (ga, loss_a, gb, loss_b, batch)

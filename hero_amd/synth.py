@@ -93,11 +93,13 @@ MASK_ID = 4      # any in-vocabulary id stands in for <mask>; the token it repla
 
 
 def make_pretrain_batches(name="D2", vfeat_dim=4352, vocab=50272, seed=1, device="cpu", mask_prob=0.15,
-                          queries_per_video=5):
+                          queries_per_video=5, videos=None):
     """One synthetic batch per pre-training task on the same videos, with the batch keys of the reference's
     collates: 'mlm' (data/mlm.py:134-176), 'mfm-nce' (data/mfm.py:77-97), 'fom' (data/fom.py:50-93), 'vsm'
     (data/vsm.py:105-145: `queries_per_video` queries for every video)."""
     sh = dict(SHAPES[name])
+    if videos is not None:
+        sh["videos"] = videos
     gen = torch.Generator().manual_seed(seed)
     B = sh["videos"]
     subs = [[(list(range(s * sh["fps"], (s + 1) * sh["fps"])), sh["toks"]) for s in range(sh["subs"])]

@@ -338,19 +338,27 @@ def _host_group():
     return _HOST_GROUP[1]
 
 
+# Every rank feeds batches of the same padded shape (fixed-shape training such as the bench's D2 batches, or a captured
+# hipGraph): the per-forward size exchange below is skipped and every rank's sizes are taken to be this rank's.
+UNIFORM_SHAPES = [False]
+
+
 def gather_negatives(query, context, context_mask, return_own=False):
     """All-gather (queries, L2-normalised contexts, masks) across ranks, padding contexts to the
     global max clip length.  ONE small integer all-gather carries every size needed.
     return_own: also return (first video, number of videos) of this rank inside the gathered set."""
     n = world_size()
-    # the sizes are host values (tensor shapes): exchange them on the host (gloo side group) so the
-    # forward pass has no device synchronisation in it
-    hg = _host_group()
-    meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]], dtype=torch.int64,
-                        device=query.device if hg == "device" else "cpu")
-    metas = [torch.empty_like(meta) for _ in range(n)]
-    dist.all_gather(metas, meta, group=None if hg == "device" else hg)
-    metas = torch.stack(metas).tolist()
+    if UNIFORM_SHAPES[0]:
+        metas = [[query.shape[0], context.shape[0], context.shape[1]]] * n
+    else:
+        # the sizes are host values (tensor shapes): exchange them on the host (gloo side group) so the
+        # forward pass has no device synchronisation in it
+        hg = _host_group()
+        meta = torch.tensor([query.shape[0], context.shape[0], context.shape[1]], dtype=torch.int64,
+                            device=query.device if hg == "device" else "cpu")
+        metas = [torch.empty_like(meta) for _ in range(n)]
+        dist.all_gather(metas, meta, group=None if hg == "device" else hg)
+        metas = torch.stack(metas).tolist()
     nq = [m[0] for m in metas]
     nv = [m[1] for m in metas]
     max_len = max(m[2] for m in metas)

@@ -220,8 +220,12 @@ def mlm_scores(batch, P, cfg, prefix="v_encoder.f_encoder"):
     return lm_head(seq[batch["txt_mask_tgt"]], P, prefix + ".lm_head")
 
 
-def mlm_loss(batch, P, cfg):
-    return F.cross_entropy(mlm_scores(batch, P, cfg), batch["txt_labels"], reduction="none")
+def mlm_loss(batch, P, cfg, vocab_pad=0):
+    """vocab_pad: columns appended by pad_vocab() and stripped before the loss (encoder.py:224-233, 366-367)."""
+    scores = mlm_scores(batch, P, cfg)
+    if vocab_pad:
+        scores = scores[:, :-vocab_pad]
+    return F.cross_entropy(scores, batch["txt_labels"], reduction="none")
 
 
 def feat_regress(x, P, prefix="v_encoder.feat_regress"):
@@ -306,9 +310,16 @@ def video_level_scores(mod_q, ctx, ctx_mask):
     return mask_logits(s, m).max(dim=1)[0]
 
 
-def video_level_loss(scores, margin=0.1, hard=None):
-    """get_video_level_loss, hinge + use_all_neg, 'mean' (pretrain.py:203-292).
+def video_level_loss(scores, margin=0.1, hard=None, ranking="hinge"):
+    """get_video_level_loss, use_all_neg, 'mean' (pretrain.py:203-292) with get_ranking_loss
+    (pretrain.py:340-362): 'hinge' max(0, margin + neg - pos) or 'lse' log(1 + exp(neg - pos)).
     hard = (pool_size, weight) or None."""
+    if ranking == "hinge":
+        rl = lambda pos, neg: torch.clamp(margin + neg - pos, min=0)      # noqa: E731
+    elif ranking == "lse":
+        rl = lambda pos, neg: torch.log1p(torch.exp(neg - pos))           # noqa: E731
+    else:
+        raise NotImplementedError("Only support 'hinge' and 'lse'")
     nq, nv = scores.shape
     per = nq // nv
     if nv == 1:
@@ -319,20 +330,21 @@ def video_level_loss(scores, margin=0.1, hard=None):
     masked = scores.clone()
     masked[torch.arange(nq), own] = 999
     neg_ctx = masked.sort(dim=1, descending=True)[0][:, 1:]          # (nq, nv-1)
-    l_ctx = torch.clamp(margin + neg_ctx - pos[:, None], min=0)
+    l_ctx = rl(pos[:, None], neg_ctx)
     neg_q = masked.t().sort(dim=1, descending=True)[0][:, per:]      # (nv, nq-per)
-    l_q = torch.clamp(margin + neg_q[:, None, :] - pos.view(nv, per, 1), min=0)
+    l_q = rl(pos.view(nv, per, 1), neg_q[:, None, :])
     l_q = l_q.reshape(nq, -1)
     if hard is not None:
-        for t in (l_ctx, l_q):
+        def weigh(t):
             w = torch.full_like(t, 0.1)
             w[:, :hard[0]] = hard[1]
-            t.mul_(w)
+            return t * w
+        l_ctx, l_q = weigh(l_ctx), weigh(l_q)
     return l_ctx.mean(1).mean(0), l_q.mean(1).mean(0)
 
 
 def vsm_losses(batch, P, cfg, lw_st_ed=0.01, lw_neg_ctx=8.0, lw_neg_q=8.0,
-               margin=0.1, hard=None, p_drop=0.0):
+               margin=0.1, hard=None, p_drop=0.0, ranking="hinge"):
     """HeroForPretraining.forward('vsm'), training branch (pretrain.py:62-116)."""
     frames = forward_repr(batch, P, cfg, p_drop=p_drop)
     q_seq = f_encoder_txt(batch["query_input_ids"], batch["query_pos_ids"],
@@ -344,7 +356,7 @@ def vsm_losses(batch, P, cfg, lw_st_ed=0.01, lw_neg_ctx=8.0, lw_neg_q=8.0,
     l_st_ed = (F.cross_entropy(st, tg[:, 0], ignore_index=-1)
                + F.cross_entropy(ed, tg[:, 1], ignore_index=-1))
     sc = video_level_scores(mod_q, frames, batch["c_attn_masks"])
-    l_ctx, l_q = video_level_loss(sc, margin, hard)
+    l_ctx, l_q = video_level_loss(sc, margin, hard, ranking)
     return lw_st_ed * l_st_ed, lw_neg_ctx * l_ctx, lw_neg_q * l_q
 
 

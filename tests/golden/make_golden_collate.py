@@ -207,6 +207,27 @@ def main():
                 "narrow.model.repr": rep.numpy(), "narrow.model.txt": txt.numpy(),
                 "narrow.model.loss_st_ed": l_st.numpy(), "narrow.model.loss_neg_ctx": l_ctx.numpy(),
                 "narrow.model.loss_neg_q": l_q.numpy()})
+    # the smooth ranking loss with hard-negative weighting (ranking_loss_type = "lse", model/pretrain.py:203-292, 340-362):
+    # losses and gradients of the same batch - pins the oracle's lse / hard-negative branch
+    lse = HeroForVcmr.from_pretrained(
+        os.path.join(HERE, "tiny_config.json"), state_dict=sd, vfeat_dim=int(z["__vfeat__"]),
+        max_frm_seq_len=int(z["__max_frm__"]), lw_neg_ctx=8.0, lw_neg_q=8.0, lw_st_ed=0.01,
+        ranking_loss_type="lse", use_hard_negative=True, hard_pool_size=1, hard_neg_weight=10, margin=0.1,
+        use_all_neg=True, drop_svmr_prob=0.0)
+    lse.train()
+    for m_ in lse.modules():
+        if isinstance(m_, torch.nn.Dropout):
+            m_.p = 0.0
+    a_, b_, c_ = lse(batch, task="tvr", compute_loss=True)
+    (a_ + b_ + c_).mean().backward()
+    lp = dict(lse.named_parameters())
+    out.update({"narrow.lse.loss_st_ed": a_.detach().numpy(), "narrow.lse.loss_neg_ctx": b_.detach().numpy(),
+                "narrow.lse.loss_neg_q": c_.detach().numpy()})
+    for n_ in ("video_query_linear.weight", "q_feat_attn.query_input_proj.net.1.weight",
+               "v_encoder.c_encoder.encoder.layer.0.output.dense.weight",
+               "v_encoder.f_encoder.encoder.layer.1.attention.self.key.weight"):
+        out["narrow.lse.grad." + n_] = lp[n_].grad.numpy().copy()
+    print("narrow lse + hard negatives:", float(a_), float(b_), float(c_))
     print("narrow: f_attn_masks", tuple(batch["f_attn_masks"].shape), "max_vl + max_sl =",
           batch["f_v_feats"].shape[1] + batch["f_sub_input_ids"].shape[1], "losses", l_st.tolist(), l_ctx.tolist(), l_q.tolist())
 

@@ -98,3 +98,22 @@ def test_lengths_describe_the_batch():
         row = [1 if (p < nf + nt if nf else 1 <= p < 1 + nt) else 0 for p in range(W)]
         assert got["f_attn_masks"][r].tolist() == row
     assert ln["vid_nfrm"].tolist() == got["c_attn_masks"].sum(1).tolist()
+
+
+def test_oracle_lse_hard_negative_branch_against_reference():
+    """ranking_loss_type = 'lse' with hard-negative weighting (model/pretrain.py:203-292, 340-362): the oracle's
+    losses AND gradients on the narrow reference batch equal the reference's."""
+    from oracle import hero_oracle as O
+    P, cfgj, vfeat, max_frm = O.load_npz_model(os.path.join(GOLDEN, "tiny_model.npz"))
+    cfg = O.cfg_from_json(cfgj)
+    b = ref_batch("narrow")
+    Pq = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("pad")) for k, v in P.items()}
+    losses = O.vsm_losses(b, Pq, cfg, hard=(1, 10.0), ranking="lse")
+    for got, key in zip(losses, ("loss_st_ed", "loss_neg_ctx", "loss_neg_q")):
+        np.testing.assert_allclose(got.detach().numpy(), Z["narrow.lse." + key], rtol=1e-5, atol=1e-6)
+    sum(losses).backward()
+    names = [k[len("narrow.lse.grad."):] for k in Z.files if k.startswith("narrow.lse.grad.")]
+    assert len(names) == 4
+    for n in names:
+        want = torch.from_numpy(Z["narrow.lse.grad." + n])
+        assert (Pq[n].grad - want).abs().max() <= 1e-5 * want.abs().max() + 1e-7, n

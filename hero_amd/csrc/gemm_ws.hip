@@ -57,6 +57,25 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 constexpr int NS = 3;                 // ring stages
 constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-sum fold
 
+// Cache policy of the epilogue stores (buffer-store aux bits; 2 = nt: streaming, no allocation priority in the L2).
+// Measured on the bench step (same box): both K,K outputs nt 52.8 us per launch / 6.96 ms per step against 54.7 / 7.05
+// with the default policy - the output of a tile is not read again by this kernel, and the panels the other CUs are
+// re-reading stay in the L2.
+#ifndef HERO_WS_STORE_AUX
+#define HERO_WS_STORE_AUX 2          // the main output of a K,K tile
+#endif
+#ifndef HERO_WS_STORE_AUX2
+#define HERO_WS_STORE_AUX2 2         // the saved pre-activation (read again only in the backward pass)
+#endif
+#ifndef HERO_WS_LOAD_AUX_A
+#define HERO_WS_LOAD_AUX_A 0         // cache policy of the direct-to-LDS operand loads (lab)
+#endif
+#ifndef HERO_WS_LOAD_AUX_B
+#define HERO_WS_LOAD_AUX_B 0
+#endif
+#ifndef HERO_WS_STORE_DW
+#define HERO_WS_STORE_DW 0           // dW tiles of the batched wgrad (read again by the optimiser)
+#endif
 #define HERO_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -202,10 +221,10 @@ struct Loader {
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, rb_left, 0x00020000);
 #pragma unroll
     for (int i = 0; i < G::PA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, HERO_WS_LOAD_AUX_A);
 #pragma unroll
     for (int i = 0; i < G::PB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, HERO_WS_LOAD_AUX_B);
     fill += G::STAGE;
     if (fill == NS * G::STAGE) fill = 0;
     if (++ik == ic.nk) {
@@ -371,9 +390,9 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
       const unsigned vo = ok[it] ? (unsigned)(tile_row(p, r0 + it * RPI) * g.ldc + c8 * 8) * 2u : 0xffffffffu;
       if (EK & EK_GELU) {
         const uint4 u = auxv[(EK & EK_GELU) ? it : 0];
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{u.x, u.y, u.z, u.w}, rsx, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{u.x, u.y, u.z, u.w}, rsx, vo, 0, HERO_WS_STORE_AUX2);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{outv[it].x, outv[it].y, outv[it].z, outv[it].w}, rsc, vo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{outv[it].x, outv[it].y, outv[it].z, outv[it].w}, rsc, vo, 0, HERO_WS_STORE_AUX);
     }
     wait_lds();
     WS_T(trace_item, 5 + 4 * p, wave, lane);
@@ -465,28 +484,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
+  // Read order a[0], b[0..], a[1..]: the MFMAs of the NEXT slice run (i outer, j inner), the reads are spread over the
+  // MFMAs of the current slice in this order, so every fragment is requested >= 7 MFMAs (224 cycles) before its first
+  // use (a[0..], b[0..] order: 5 MFMAs for b[0] - less than the LDS latency beside the DMA writes).
   auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
-    if (!TR) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(st + (ao[i] ^ (ks << 5)));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(st + (bo[j] ^ (ks << 5)));
-    } else {
-      typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+    auto ra = [&](int i) {
+      if (!TR) {
+        a[i] = *reinterpret_cast<const bf16x8_t*>(st + (ao[i] ^ (ks << 5)));
+      } else {
         const char* q = st + ao[i] + ks * 16 * (G::BM * 2);
         const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
         const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BM * 2)));
         a[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
+    };
+    auto rb = [&](int j) {
+      if (!TR) {
+        b[j] = *reinterpret_cast<const bf16x8_t*>(st + (bo[j] ^ (ks << 5)));
+      } else {
         const char* q = st + bo[j] + ks * 16 * (G::BN * 2);
         const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
         const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BN * 2)));
         b[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+    };
+    if (!TR) {                                      // K,K: the MFMA is (b[j], a[i]) but the loop order is the same
+      ra(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) rb(j);
+#pragma unroll
+      for (int i = 1; i < TM; ++i) ra(i);
+    } else {
+      ra(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) rb(j);
+#pragma unroll
+      for (int i = 1; i < TM; ++i) ra(i);
     }
   };
   f32x16_t acc[TM][TN];
@@ -663,10 +697,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, rb_left, 0x00020000);
 #pragma unroll
       for (int i = 0; i < G::PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, HERO_WS_LOAD_AUX_A);
 #pragma unroll
       for (int i = 0; i < G::PB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, HERO_WS_LOAD_AUX_B);
       fill += G::STAGE;
       if (fill == NS * G::STAGE) fill = 0;
       ++pos;
@@ -711,14 +745,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
   bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
-  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {       // order a[0], b[..], a[1..]: see gemm_ws_kernel
+    auto ra = [&](int i) {
       const char* q = st + ao[i] + ks * 16 * (G::BM * 2);
       const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BM * 2)));
       a[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
+    };
+    ra(0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const char* q = st + bo[j] + ks * 16 * (G::BN * 2);
@@ -726,6 +760,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BN * 2)));
       b[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
+#pragma unroll
+    for (int i = 1; i < TM; ++i) ra(i);
   };
   f32x16_t acc[TM][TN];
   auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
@@ -913,8 +949,8 @@ __device__ __forceinline__ void epilogue_acc(const WsbProb& P, const WsbItem& it
 #endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v0[i][0]), __float_as_uint(v0[i][1]), __float_as_uint(v0[i][2]), __float_as_uint(v0[i][3])}, rc, voff[h + i], 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v1[i][0]), __float_as_uint(v1[i][1]), __float_as_uint(v1[i][2]), __float_as_uint(v1[i][3])}, rc, voff[h + i], 16, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v0[i][0]), __float_as_uint(v0[i][1]), __float_as_uint(v0[i][2]), __float_as_uint(v0[i][3])}, rc, voff[h + i], 0, HERO_WS_STORE_DW);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v1[i][0]), __float_as_uint(v1[i][1]), __float_as_uint(v1[i][2]), __float_as_uint(v1[i][3])}, rc, voff[h + i], 16, HERO_WS_STORE_DW);
         }
       }
     } else {
@@ -999,10 +1035,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifndef HERO_WSB_NOLOADS        // lab ablations (tools/lab/build_variants.sh): results are garbage, timing only
 #pragma unroll
       for (int i = 0; i < G::PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, HERO_LDS_PTR(buf + (w * G::PA + i) * 1024), 16, goa[i], 0, 0, HERO_WS_LOAD_AUX_A);
 #pragma unroll
       for (int i = 0; i < G::PB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, HERO_WS_LOAD_AUX_B);
 #else
       (void)ra; (void)rb; (void)buf;
 #endif
@@ -1028,7 +1064,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const WsbItem it = g.items[(size_t)r * nwg + wg];
       for (int t = 0; t < it.nk; ++t) {
         if (issue()) wait_vm<G::PW>(); else wait_vm<0>();
+#ifndef HERO_WSB_NOBAR
         __builtin_amdgcn_s_barrier();                                 // B(u)
+#endif
         if (t + 1 < it.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
       }
 #ifndef HERO_WSB_NOEPI
@@ -1059,17 +1097,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
   bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
-  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
+  auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {       // order a[0], b[..], a[1..]: see gemm_ws_kernel
 #ifdef HERO_WSB_NOLDF
     return;
 #endif
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    auto ra = [&](int i) {
       const char* q = st + ao[i] + ks * 16 * (G::BM * 2);
       const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q));
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BM * 2)));
       a[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
+    };
+    ra(0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const char* q = st + bo[j] + ks * 16 * (G::BN * 2);
@@ -1077,6 +1115,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(q + 4 * (G::BN * 2)));
       b[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
+#pragma unroll
+    for (int i = 1; i < TM; ++i) ra(i);
   };
   f32x16_t acc[TM][TN];
   auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
@@ -1127,7 +1167,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       wait_lds();
+#ifndef HERO_WSB_NOBAR
       __builtin_amdgcn_s_barrier();                                   // B(u)
+#endif
       __builtin_amdgcn_sched_barrier(0);
       ldf(a0, b0, nxt, 0);            // unconditional (a branch around it doubles the MFMA code and spills): after the
       mma(a1, b1);                    // item's last step this reads the landed first stage of the next item and is

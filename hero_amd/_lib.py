@@ -18,7 +18,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
 EXPORTS = [
     "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
-    "hero_colsum", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len",
+    "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
@@ -72,7 +72,12 @@ class LnBwd(C.Structure):
                 ("dx_dropped", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("grad_beta", C.c_float), ("workspace", C.c_void_p),
                 ("rows", C.c_int), ("cols", C.c_int), ("x_dtype", C.c_int), ("dtype", C.c_int),
-                ("dropout_out", Dropout), ("dropout_in", Dropout), ("dbias_in", C.c_void_p)]
+                ("dropout_out", Dropout), ("dropout_in", Dropout), ("dbias_in", C.c_void_p), ("defer_fold", C.c_int)]
+
+
+class Colsum(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
+                ("dtype", C.c_int), ("beta", C.c_float)]
 
 
 class Attn(C.Structure):
@@ -163,6 +168,10 @@ def lib():
         L.hero_last_error.restype = C.c_char_p
         L.hero_layernorm_bwd_workspace_bytes.restype = C.c_size_t
         L.hero_colsum_workspace_bytes.restype = C.c_size_t
+        L.hero_colsum_multi_workspace_bytes.restype = C.c_size_t
+        L.hero_colsum_multi_workspace_bytes.argtypes = [C.POINTER(Colsum), C.c_int]
+        L.hero_colsum_multi.argtypes = [C.POINTER(Colsum), C.c_int, C.c_void_p, C.c_void_p]
+        L.hero_layernorm_bwd_blocks.argtypes = [C.c_int]
         L.hero_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [
             C.POINTER(GemmEpilogue), C.c_void_p]
         L.hero_wgrad_group.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -721,13 +721,14 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
     } else if (need <= 1) { CALLF(1); } else if (need <= 2) { CALLF(2); } else if (need <= 3) { CALLF(3); } else { CALLF(4); }
 #undef CALLF
     int rc = check_launch("hero_layernorm_bwd(fused)");
-    if (rc) return rc;
+    if (rc || a->defer_fold) return rc;
     const int zs = (a->grad_beta == 1.f && nblk >= 128) ? 8 : 1;
     hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 63) / 64, 3, zs), dim3(256), 0, s, partial, a->dgamma, a->dbeta,
                        a->dbias_in, a->cols, nblk, a->grad_beta);
     return check_launch("hero_layernorm_bwd(final3)");
   }
   HERO_REQUIRE(!a->dbias_in, "hero_layernorm_bwd: dbias_in needs cols <= 1024");
+  HERO_REQUIRE(!a->defer_fold, "hero_layernorm_bwd: defer_fold needs the fused path (cols <= 1024, dx or dbias_in wanted)");
   if (a->dx || a->dx_dropped) {
     const dim3 grid((a->rows + 3) / 4), block(256);
 #define CALL(V)                                                                                                      \
@@ -751,6 +752,151 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
     return HERO_ERR_UNSUPPORTED;
   }
   return HERO_OK;
+}
+
+extern "C" int hero_layernorm_bwd_blocks(int rows) {
+  int nblk = (rows + 3) / 4;
+  return nblk > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nblk;
+}
+
+// ---- many column sums, two launches --------------------------------------------------------------------------------
+struct ColsumMulti {
+  HeroColsum p[HERO_COLSUM_MULTI_MAX];
+  int blk0[HERO_COLSUM_MULTI_MAX + 1];    // first workgroup of problem i (stage 1: col-blocks x chunks; stage 2: 16-column groups)
+  int woff[HERO_COLSUM_MULTI_MAX];        // partial sums of problem i: workspace + woff[i], [nchunks][cols]
+  int rpc[HERO_COLSUM_MULTI_MAX];         // rows per chunk
+  int n;
+};
+
+__device__ __forceinline__ int colsum_find(const ColsumMulti& a, int b) {
+  int lo = 0, hi = a.n - 1;                // uniform binary search over <= 64 prefix entries
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.blk0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <typename T>
+__device__ __forceinline__ float4 colsum_chunk(const T* src, int ld, int c, int r0, int r1, int ty) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int r = r0 + ty;
+  for (; r + 12 < r1; r += 16) {           // four rows per trip, their loads issued together
+    float4 d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = V4<T>::ld(src + (size_t)(r + 4 * u) * ld + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += d[u].x; s.y += d[u].y; s.z += d[u].z; s.w += d[u].w; }
+  }
+  for (; r < r1; r += 4) {
+    const float4 d = V4<T>::ld(src + (size_t)r * ld + c);
+    s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void colsum_multi_part_kernel(ColsumMulti a, float* ws) {
+  __shared__ float4 red[4][64];
+  const int pi = colsum_find(a, blockIdx.x);
+  const HeroColsum P = a.p[pi];
+  const int ncb = (P.cols + 255) / 256;
+  const int local = blockIdx.x - a.blk0[pi], cb = local % ncb, chunk = local / ncb;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (cb * 64 + tx) * 4;
+  const int r0 = chunk * a.rpc[pi], r1 = min(P.rows, r0 + a.rpc[pi]);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < P.cols) {
+    if (P.dtype == HERO_BF16) s = colsum_chunk(static_cast<const bf16_t*>(P.src), P.ld, c, r0, r1, ty);
+    else s = colsum_chunk(static_cast<const float*>(P.src), P.ld, c, r0, r1, ty);
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < P.cols) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const float4 v = red[k][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    *reinterpret_cast<float4*>(ws + a.woff[pi] + (size_t)chunk * P.cols + c) = s;
+  }
+}
+
+// dst[c] = beta*dst[c] + sum over the chunks, fixed order: 16 columns x 16 chunk-lanes per workgroup
+__global__ __launch_bounds__(256) void colsum_multi_fold_kernel(ColsumMulti a, const float* ws) {
+  const int pi = colsum_find(a, blockIdx.x);
+  const HeroColsum P = a.p[pi];
+  const int nchunks = (P.rows + a.rpc[pi] - 1) / a.rpc[pi];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = (blockIdx.x - a.blk0[pi]) * 16 + cl;
+  const float* part = ws + a.woff[pi];
+  float s = 0.f;
+  if (c < P.cols) {
+    int k = kl;
+    for (; k + 48 < nchunks; k += 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(k + 16 * u) * P.cols + c];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (; k < nchunks; k += 16) s += part[(size_t)k * P.cols + c];
+  }
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+  __shared__ float red[4][16];
+  if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < P.cols) {
+    s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    P.dst[c] = (P.beta != 0.f ? P.beta * P.dst[c] : 0.f) + s;
+  }
+}
+
+static int colsum_multi_plan(const HeroColsum* p, int n, ColsumMulti* a, int* fold_blocks, size_t* ws_floats) {
+  size_t off = 0;
+  int b1 = 0;
+  for (int i = 0; i < n; ++i) {
+    int rpc;
+    const int nchunks = chunking(p[i].rows, &rpc);
+    if (a) { a->p[i] = p[i]; a->blk0[i] = b1; a->woff[i] = (int)off; a->rpc[i] = rpc; }
+    b1 += ((p[i].cols + 255) / 256) * nchunks;
+    off += (size_t)nchunks * p[i].cols;
+  }
+  if (a) { a->blk0[n] = b1; a->n = n; }
+  if (fold_blocks) {
+    int b2 = 0;
+    for (int i = 0; i < n; ++i) b2 += (p[i].cols + 15) / 16;
+    *fold_blocks = b2;
+  }
+  *ws_floats = off;
+  return b1;
+}
+
+extern "C" size_t hero_colsum_multi_workspace_bytes(const HeroColsum* p, int n) {
+  if (!p || n < 1 || n > HERO_COLSUM_MULTI_MAX) return 0;
+  size_t fl = 0;
+  colsum_multi_plan(p, n, nullptr, nullptr, &fl);
+  return fl * sizeof(float);
+}
+
+extern "C" int hero_colsum_multi(const HeroColsum* p, int n, void* workspace, hero_stream_t stream) {
+  HERO_REQUIRE(p && workspace && n >= 1 && n <= HERO_COLSUM_MULTI_MAX, "hero_colsum_multi: 1..%d problems and a workspace", HERO_COLSUM_MULTI_MAX);
+  for (int i = 0; i < n; ++i) {
+    HERO_REQUIRE(p[i].src && p[i].dst && p[i].rows > 0 && p[i].cols > 0 && p[i].cols % 4 == 0 && p[i].ld % 4 == 0 &&
+                     (p[i].dtype == HERO_BF16 || p[i].dtype == HERO_F32) && ((uintptr_t)p[i].src & 7) == 0,
+                 "hero_colsum_multi: bad problem %d", i);
+  }
+  ColsumMulti a, f;
+  size_t fl = 0;
+  int fold_blocks = 0;
+  const int part_blocks = colsum_multi_plan(p, n, &a, &fold_blocks, &fl);
+  HERO_REQUIRE(fl < 0x7fffffffull, "hero_colsum_multi: workspace too large");
+  f = a;                                    // stage 2 walks 16-column groups instead
+  int b2 = 0;
+  for (int i = 0; i < n; ++i) { f.blk0[i] = b2; b2 += (p[i].cols + 15) / 16; }
+  f.blk0[n] = b2;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colsum_multi_part_kernel, dim3(part_blocks), dim3(256), 0, s, a, static_cast<float*>(workspace));
+  int rc = check_launch("hero_colsum_multi(partials)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_multi_fold_kernel, dim3(fold_blocks), dim3(256), 0, s, f, static_cast<const float*>(workspace));
+  return check_launch("hero_colsum_multi(fold)");
 }
 
 extern "C" int hero_colsum(const void* x, float* out, int rows, int cols, int ld, int dtype, float beta, void* workspace,

@@ -164,14 +164,31 @@ typedef struct HeroLnBwd {
   HeroDropout dropout_in;  /* dropout of the GEMM epilogue that produced x (for dx_dropped)     */
   float* dbias_in;         /* optional [cols] (cols <= 1024): += sum_rows dx*mask(dropout_in) =     */
                            /* bias gradient of the linear layer feeding this LN, same pass         */
+  int defer_fold;          /* 1 (fused path only: cols <= 1024 and dx wanted): leave the per-block   */
+                           /* partial sums in `workspace` as fp32 [hero_layernorm_bwd_blocks(rows)]  */
+                           /* [3][cols] (dgamma | dbeta | dbias_in) and do not touch the outputs -   */
+                           /* the caller folds them later, e.g. many at once with hero_colsum_multi  */
 } HeroLnBwd;
 size_t hero_layernorm_bwd_workspace_bytes(int rows, int cols);
+int hero_layernorm_bwd_blocks(int rows);   /* rows of the partial-sum matrix the fused backward writes */
 int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream);
 
 /* Column sum: out[c] <- beta*out[c] + sum_r x[r, c]  (bias gradients of every nn.Linear).      */
 size_t hero_colsum_workspace_bytes(int rows, int cols);
 int hero_colsum(const void* x, float* out, int rows, int cols, int ld, int dtype, float beta,
                 void* workspace, hero_stream_t stream);
+/* Many column sums in TWO launches (row-chunk partials, then a fixed-order fold: deterministic, no atomics): the   */
+/* bias gradients of all nn.Linear layers of a backward pass (model/layers.py:125-127, 175-179, 236-239, 250-254)   */
+/* and the deferred LayerNorm partial folds, queued and flushed together.  dst[c] <- beta*dst[c] + sum_r src[r,c]. */
+#define HERO_COLSUM_MULTI_MAX 64
+typedef struct HeroColsum {
+  const void* src;   /* [rows, ld] dtype, the `cols` columns starting at this pointer (16-byte aligned) */
+  float* dst;        /* [cols]                                                                         */
+  int rows, cols, ld, dtype;   /* cols, ld multiples of 4                                              */
+  float beta;
+} HeroColsum;
+size_t hero_colsum_multi_workspace_bytes(const HeroColsum* p, int n);
+int hero_colsum_multi(const HeroColsum* p, int n, void* workspace, hero_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Masked multi-head self-attention, head size 64 — model/layers.py:129-160                     */

@@ -616,3 +616,56 @@ def test_adamw_matches_oracle(HF, Lb):
     gn = g.norm().cpu()
     O.adamw_step(P2, {"w": g.cpu() * (1.0 / (gn + 1e-6))}, st2, lr=1e-3, step=1, wd=0.0)
     torch.testing.assert_close(q.detach().cpu(), P2["w"], rtol=1e-5, atol=1e-6)
+
+
+def test_colsum_multi_and_deferred_layernorm_fold(HF, Lb):
+    """hero_colsum_multi: many column sums (bf16 activations with a column offset, fp32 partial matrices, accumulate /
+    overwrite) in two launches, bit-reproducible; hero_layernorm_bwd(defer_fold) leaves the partials the multi-fold
+    then turns into the same dgamma / dbeta / dbias the immediate fold gives."""
+    import ctypes as C
+    srcs = [rnd(12000, 2304, dtype=torch.bfloat16, seed=1), rnd(1920, 768, dtype=torch.bfloat16, seed=2),
+            rnd(1000, 3 * 768, dtype=torch.float32, seed=3), rnd(37, 16, dtype=torch.float32, seed=4)]
+    specs = [(srcs[0], 768, 1536, 1.0), (srcs[1], 0, 768, 0.0), (srcs[2], 768, 768, 1.0), (srcs[3], 0, 16, 1.0)]
+    outs = [torch.full((n,), 0.5, device="cuda") for _, _, n, _ in specs]
+    probs = (Lb.Colsum * len(specs))()
+    for i, (t, c0, n, beta) in enumerate(specs):
+        probs[i] = Lb.Colsum(t.data_ptr() + c0 * t.element_size(), outs[i].data_ptr(), t.shape[0], n, t.shape[1], Lb.dt(t), beta)
+    ws = torch.empty(Lb.lib().hero_colsum_multi_workspace_bytes(probs, len(specs)) // 4 + 1, device="cuda")
+    first = None
+    for rep in range(3):
+        for o in outs:
+            o.fill_(0.5)
+        Lb.check(Lb.lib().hero_colsum_multi(probs, len(specs), ws.data_ptr(), Lb.stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = [o.clone() for o in outs]
+        assert all(torch.equal(a, b) for a, b in zip(outs, first))
+    for (t, c0, n, beta), o in zip(specs, outs):
+        ref = t.float()[:, c0:c0 + n].sum(0) + 0.5 * beta
+        torch.testing.assert_close(o, ref, rtol=2e-5, atol=2e-3)
+    # deferred LayerNorm fold == immediate fold
+    rows, cols = 4000, 768
+    x, dy = rnd(rows, cols, dtype=torch.bfloat16, seed=5), rnd(rows, cols, dtype=torch.bfloat16, seed=6)
+    gamma = rnd(cols, seed=7)
+    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    res = []
+    for defer in (0, 1):
+        dg, db, dbi = (torch.zeros(cols, device="cuda") for _ in range(3))
+        dx = torch.empty_like(dy)
+        nblk = Lb.lib().hero_layernorm_bwd_blocks(rows)
+        part = torch.empty(max(nblk, 1024) * 3 * cols, device="cuda")
+        a = Lb.LnBwd()
+        a.x, a.dy, a.gamma, a.mean, a.rstd = x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        a.dx, a.dgamma, a.dbeta, a.dbias_in = dx.data_ptr(), dg.data_ptr(), db.data_ptr(), dbi.data_ptr()
+        a.grad_beta, a.workspace, a.rows, a.cols, a.x_dtype, a.dtype, a.defer_fold = 1.0, part.data_ptr(), rows, cols, Lb.BF16, Lb.BF16, defer
+        a.dropout_out.scale = a.dropout_in.scale = 1.0
+        Lb.check(Lb.lib().hero_layernorm_bwd(C.byref(a), Lb.stream()))
+        if defer:
+            p3 = (Lb.Colsum * 3)(*[Lb.Colsum(part.data_ptr() + 4 * k * cols, t.data_ptr(), nblk, cols, 3 * cols, Lb.F32, 1.0)
+                                   for k, t in enumerate((dg, db, dbi))])
+            w3 = torch.empty(Lb.lib().hero_colsum_multi_workspace_bytes(p3, 3) // 4 + 1, device="cuda")
+            Lb.check(Lb.lib().hero_colsum_multi(p3, 3, w3.data_ptr(), Lb.stream()))
+        torch.cuda.synchronize()
+        res.append((dg.clone(), db.clone(), dbi.clone()))
+    for a_, b_ in zip(res[0], res[1]):
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-3)

@@ -897,7 +897,9 @@ class EmbedLnFn(torch.autograd.Function):
             if _is_param(tab):
                 per = getattr(idx, "_hero_period", 0) if idx is not None else 0
                 if idx is None:
-                    k_colsum(dx, out=SINK.dst(tab).view(-1, tab.shape[-1])[0], beta=1.0)
+                    k_colsum(dx, out=SINK.dst(tab).view(-1, tab.shape[-1])[0], beta=1.0, on_done=lambda tab=tab: SINK.done(tab))
+                    grads_t.append(None)
+                    continue
                 elif per and dx.shape[0] % per == 0 and dx.shape[0] // per >= 8:
                     # periodic index (position ids broadcast over the sequences): fold the repeats with a
                     # column sum over [S, period*D], then scatter `period` rows - not S-way contended atomics
@@ -998,12 +1000,10 @@ def _qkv_bwd(dqkv, x2, qkv_params, D):
     if gw is not None:
         k_wgrad(dqkv, x2, out=gw, beta=1.0, on_done=lambda: [SINK.done(p) for p in ws])
     if gb is not None:
-        k_colsum(dqkv, out=gb.view(-1), beta=1.0)
+        k_colsum(dqkv, out=gb.view(-1), beta=1.0, on_done=lambda: [SINK.done(p) for p in bs])
     for i, (w, b) in enumerate(zip(ws, bs)):
         acc_linear_grads(dqkv, x2, None if gw is not None else w, None if gb is not None else b, col0=i * D,
                          ncols=D)
-    for p in (bs if gb is not None else ()):
-        SINK.done(p)
 
 
 class SelfAttentionFn(torch.autograd.Function):

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(HeroAttn a) {
 // Backward. LDS: K, V (padded stride), Q, dO (stride 64), and for a chunk of R query rows the
 // matrices dS[R][Lp] (already scaled) and Pd[R][Lp] (dropped probabilities).  dK/dV accumulate in
 // registers across chunks: wave w owns keys w, w+4, ... (KPW of them per wave).
-template <typename T, int LPK, int KPW>
+// QO_GLOBAL (round 3: fp32 up to L = 256, the config-5 length of the parity mode): Q and dO are read from global
+// memory (L2) row by row instead of being staged, which leaves the LDS to K, V and the row chunk.
+template <typename T, int LPK, int KPW, bool QO_GLOBAL>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DPL = DH / LPK, KPP = 64 / LPK, STR = KvLay<T>::STRIDE;
@@ -179,17 +181,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
   const int Lp = (L + 3) & ~3;
   T* Ks = reinterpret_cast<T*>(smem);
   T* Vs = Ks + (size_t)L * STR;
-  T* Qs = Vs + (size_t)L * STR;
-  T* Os = Qs + (size_t)L * DH;
-  float* dS = reinterpret_cast<float*>(smem + (((size_t)(2 * L * STR + 2 * L * DH) * sizeof(T)) + 15) / 16 * 16);
-  float* Pd = dS + (size_t)R * Lp;
-
   const T* qkv = static_cast<const T*>(a.qkv) + (size_t)s * L * 3 * D;
   const T* dctx = static_cast<const T*>(a.dctx) + (size_t)s * L * D + h * DH;
-  stage_head<T>(qkv + h * DH, 3 * D, L, Qs, DH);
+  const T* Qs = QO_GLOBAL ? qkv + h * DH : Vs + (size_t)L * STR;       // row i at Qs + i * QST
+  const T* Os = QO_GLOBAL ? dctx : Vs + (size_t)L * STR + (size_t)L * DH;
+  const int QST = QO_GLOBAL ? 3 * D : DH, OST = QO_GLOBAL ? D : DH;
+  float* dS = reinterpret_cast<float*>(smem + (((size_t)(2 * L * STR + (QO_GLOBAL ? 0 : 2 * L * DH)) * sizeof(T)) + 15) / 16 * 16);
+  float* Pd = dS + (size_t)R * Lp;
+
+  if (!QO_GLOBAL) {
+    stage_head<T>(qkv + h * DH, 3 * D, L, Vs + (size_t)L * STR, DH);
+    stage_head<T>(dctx, D, L, Vs + (size_t)L * STR + (size_t)L * DH, DH);
+  }
   stage_head<T>(qkv + D + h * DH, 3 * D, L, Ks, STR);
   stage_head<T>(qkv + 2 * D + h * DH, 3 * D, L, Vs, STR);
-  stage_head<T>(dctx, D, L, Os, DH);
   __syncthreads();
 
   DropCtx drop(a.dropout);
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
     for (int il = wave; il < cr; il += 4) {
       const int i = c0 + il;
       float ov[DPL];
-      lds_row_slice<T, DPL>(Os + i * DH, p, ov);
+      lds_row_slice<T, DPL>(Os + (size_t)i * OST, p, ov);
       float* dSr = dS + (size_t)il * Lp;
       float* Pdr = Pd + (size_t)il * Lp;
       float prs[MAXP], dps[MAXP];
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(HeroAttn a, int R) {
         float ak = accK[k], av = accV[k];
         for (int il = 0; il < cr; ++il) {
           const int i = c0 + il;
-          ak = fmaf(dS[(size_t)il * Lp + j], ld1<T>(Qs + i * DH + lane), ak);
-          av = fmaf(Pd[(size_t)il * Lp + j], ld1<T>(Os + i * DH + lane), av);
+          ak = fmaf(dS[(size_t)il * Lp + j], ld1<T>(Qs + (size_t)i * QST + lane), ak);
+          av = fmaf(Pd[(size_t)il * Lp + j], ld1<T>(Os + (size_t)i * OST + lane), av);
         }
         accK[k] = ak; accV[k] = av;
       }
@@ -507,8 +512,8 @@ template <typename T> static size_t fwd_lds(int L) {
   const int Lp = (L + 3) & ~3;
   return (((size_t)(2 * L * KvLay<T>::STRIDE) * sizeof(T)) + 15) / 16 * 16 + (size_t)4 * Lp * sizeof(float);
 }
-template <typename T> static size_t bwd_lds_fixed(int L) {
-  return (((size_t)(2 * L * KvLay<T>::STRIDE + 2 * L * DH) * sizeof(T)) + 15) / 16 * 16;
+template <typename T> static size_t bwd_lds_fixed(int L, bool qo_global = false) {
+  return (((size_t)(2 * L * KvLay<T>::STRIDE + (qo_global ? 0 : 2 * L * DH)) * sizeof(T)) + 15) / 16 * 16;
 }
 template <typename T> static int max_len(int backward) {
   int L = 1;
@@ -516,7 +521,7 @@ template <typename T> static int max_len(int backward) {
     while (L < 1024 && fwd_lds<T>(L + 1) <= LDS_BUDGET) ++L;
     return L;
   }
-  while (L < 256 && bwd_lds_fixed<T>(L + 1) + (size_t)2 * 4 * ((L + 4) & ~3) * sizeof(float) <= LDS_BUDGET) ++L;
+  while (L < 256 && bwd_lds_fixed<T>(L + 1, true) + (size_t)2 * 4 * ((L + 4) & ~3) * sizeof(float) <= LDS_BUDGET) ++L;
   return L;
 }
 
@@ -531,10 +536,11 @@ static int launch_fwd(const HeroAttn& a, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
   return check_launch("hero_attention_fwd");
 }
-template <typename T, int LPK, int KPW>
+template <typename T, int LPK, int KPW, bool QO_GLOBAL = false>
 static int launch_bwd(const HeroAttn& a, hipStream_t s) {
   const int Lp = (a.L + 3) & ~3;
-  const size_t fixed = bwd_lds_fixed<T>(a.L);
+  const size_t fixed = bwd_lds_fixed<T>(a.L, QO_GLOBAL);
+  if (!QO_GLOBAL && fixed + (size_t)2 * 4 * Lp * sizeof(float) > LDS_BUDGET) return launch_bwd<T, LPK, KPW, true>(a, s);
   int R = (int)((LDS_BUDGET - fixed) / ((size_t)2 * Lp * sizeof(float)));
   if (R > a.L) R = a.L;
   R &= ~3;
@@ -542,10 +548,10 @@ static int launch_bwd(const HeroAttn& a, hipStream_t s) {
   const size_t lds = fixed + (size_t)2 * R * Lp * sizeof(float);
   static size_t attr = 65536;
   if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, LPK, KPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, LPK, KPW, QO_GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<T, LPK, KPW>), dim3(a.S * a.H), dim3(256), lds, s, a, R);
+  hipLaunchKernelGGL((attn_bwd_kernel<T, LPK, KPW, QO_GLOBAL>), dim3(a.S * a.H), dim3(256), lds, s, a, R);
   return check_launch("hero_attention_bwd");
 }
 template <typename T, int LPK>

@@ -19,9 +19,12 @@ from tests.util import rel_err, to_dev
 
 pytestmark = pytest.mark.gpu
 
-# bf16 storage (2^-9 relative per rounding) through 9 post-LN layers; measured 1-2e-2 on HERO-base
-BF16_MAX_TOL = 6e-2      # max |a-b| / max |b| under the mask (same metric as test_gpu_parity)
-BF16_L2_TOL = 3e-2       # ||a-b||_2 / ||b||_2 under the mask: an element-weighted relative error
+# bf16 storage (2^-9 relative per rounding) through 9 post-LN layers.  Round 3: set from the measured per-layer error
+# growth (test_bf16_error_growth_per_layer prints it: L2 error 2.0e-3 after the embeddings, 4.0 / 5.3 / 6.3 / 7.1 / 7.9 /
+# 8.6e-3 after 1..6 cross-modal layers, 9.5e-3 after the 3 temporal ones; max-norm 0.5e-2 -> 1.8e-2) with ~1.6x headroom;
+# round 2 allowed 6e-2 / 3e-2.
+BF16_MAX_TOL = 3e-2      # max |a-b| / max |b| under the mask (same metric as test_gpu_parity)
+BF16_L2_TOL = 1.5e-2     # ||a-b||_2 / ||b||_2 under the mask: an element-weighted relative error
 FP32_TOL = 5e-4          # north_star: 1e-3 relative fp32
 
 HERO_BASE = {
@@ -141,6 +144,39 @@ def test_hero_base_bf16_full_d2_batch_vs_oracle():
     assert all(v < 0.06 for k, v in report.items() if k.startswith("grad.")), report
 
 
+def test_bf16_error_growth_per_layer():
+    """Where the bf16 error of the benched path comes from: the cross-modal stack truncated after 0..6 layers (HIP bf16
+    vs the fp32 oracle on the same D2 slice).  The growth must stay roughly linear in depth (post-LN renormalises every
+    layer, so errors add, they do not compound); the gates above are set from these numbers."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.synth import make_batch
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.set_grad_sink(None)
+    HF.clear_weight_cache()
+    P, model = hero_base()
+    batch = make_batch("D2", vocab=2048, seed=7, videos=4)
+    b = to_dev(batch, "cuda")
+    cfg = O.cfg_from_json(HERO_BASE)
+    enc = model.v_encoder.f_encoder.encoder
+    layers = list(enc.layer)
+    growth = []
+    try:
+        for n in range(0, 7):
+            enc.layer = torch.nn.ModuleList(layers[:n])
+            with torch.no_grad():
+                got = model.v_encoder.f_encoder(b, "repr")[0]
+                want = O.f_encoder_repr(batch, P, cfg._replace(f_layers=n))
+            growth.append((n, l2_err(got, want, batch["f_attn_masks"]), rel_err(got, want, batch["f_attn_masks"])))
+    finally:
+        enc.layer = torch.nn.ModuleList(layers)
+    print("bf16 error after n cross-modal layers (n, L2, max-norm):", [(n, round(a, 5), round(m, 5)) for n, a, m in growth])
+    l2 = [a for _, a, _ in growth]
+    assert l2[0] < 4e-3 and l2[6] < BF16_L2_TOL
+    assert all(l2[n + 1] - l2[n] < 3e-3 for n in range(6)), growth             # additive, not compounding
+    assert max(m for _, _, m in growth) < BF16_MAX_TOL
+
+
 def long_video_batch(ragged, videos=2, vocab=2048, seed=11):
     """configs[4] shapes: 256 frames, 64 subtitles x 4 frames, 20 tokens per subtitle, 15-token queries.
     ragged: 256 / 201 frames, subtitles of 0-6 frames and 4-30 tokens, some frames matched to no subtitle."""
@@ -190,6 +226,16 @@ def test_long_video_256_frame_temporal_transformer(ragged):
     with torch.no_grad():
         f32 = model.v_encoder(b, "repr")
     assert rel_err(f32, ref_frames, batch["c_attn_masks"]) < FP32_TOL
+    # fp32 GRADIENTS at the config-5 length (round 3: the fp32 attention backward reaches L = 256 by reading Q / dO from
+    # global memory): the smooth objective of `oracle_losses_and_grads` through the 256-frame Temporal Transformer
+    model.zero_grad()
+    l32 = model(b, task="tvr", compute_loss=True)
+    objective(l32[0], model.v_encoder(b, "repr"), R).backward()
+    p32 = dict(model.named_parameters())
+    g32 = {n: l2_err(p32[n].grad, ref_grads[n]) for n in names}
+    print("fp32 gradient parity at L = 256:", json.dumps(g32))
+    assert all(v < 2e-3 for v in g32.values()), g32
+    model.zero_grad()
     # bf16 compute: matrix-core attention at L = 256 (forward + backward) against fp32 / the oracle
     hero_amd.set_compute_dtype(torch.bfloat16)
     HF.clear_weight_cache()

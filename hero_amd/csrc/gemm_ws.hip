@@ -1418,7 +1418,7 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
   }
   const int T = (int)tiles.size();
   const int full = T / nwg, rem = T % nwg;
-  if (full == 0) return 0;
+  if (full == 0 && T < nwg / 4) return 0;          // a handful of tiles: the stream-K group kernel cuts finer
   const int rounds = full + (rem ? 1 : 0);
   const int words = PLAN_HDR + rounds * nwg * 8;
   HERO_REQUIRE(plan && capacity_words >= words, "hero_wgrad_batch_plan: needs %d words, capacity %d", words, capacity_words);

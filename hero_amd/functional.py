@@ -453,7 +453,7 @@ def wgrad_flush():
             K = x2.shape[1]
             probs[i] = L.WgradProblem(L.ptr(dy2) + col0 * dy2.element_size(), L.ptr(x2), L.ptr(out), N, K,
                                       dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32))
-        plan = _wgrad_plan(probs, n, rows, group[0][0].device) if (n > 4 and dtype == torch.bfloat16) else None
+        plan = _wgrad_plan(probs, n, rows, group[0][0].device) if dtype == torch.bfloat16 else None
         if plan is not None:
             L.check(L.lib().hero_wgrad_batch(probs, n, rows, L.BF16, L.ptr(plan[0]), plan[1], L.stream()))
         else:

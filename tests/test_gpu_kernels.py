@@ -273,8 +273,16 @@ def test_wgrad_batch_ragged_shapes_and_small_groups(HF, Lb):
         torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
     assert float((outs[3][768:] - 0.25).abs().max()) == 0.0          # rows of dW outside the problem are untouched
     buf = np.zeros(8 + 8 * 256 * 16, dtype=np.int32)
-    small = (Lb.WgradProblem * 2)(probs[4], probs[5])
-    assert Lb.lib().hero_wgrad_batch_plan(small, 2, rows, buf.ctypes.data, buf.size) == 0
+    small = (Lb.WgradProblem * 1)(probs[3])                          # 16 tiles: left to the stream-K group kernel
+    assert Lb.lib().hero_wgrad_batch_plan(small, 1, rows, buf.ctypes.data, buf.size) == 0
+    # a group smaller than one round of the chip (two 4352-wide projections: 184 tiles) runs as a sliced tail only
+    two = (Lb.WgradProblem * 2)(probs[0], probs[2])
+    for o in (outs[0], outs[2]):
+        o.fill_(0.25)
+    plan = _run_batch(Lb, two, 2, rows)
+    assert plan[2] == 1 and plan[6] == 184
+    for i in (0, 2):
+        torch.testing.assert_close(outs[i], dys[i].float().t() @ xs[i].float() + 0.25, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
 
 
 def test_deferred_weight_gradients_are_flushed_with_the_backward_pass(HF, Lb):

@@ -41,7 +41,7 @@ SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (4-wave tiles, K-contiguous operands: t
               8: "gemm_ws_kernel<3,3,K,K> (wave-specialised persistent 192x192 tiles: forward x W^T and dgrad dY (W^T)^T "
                  "of the M = 12000 row batch, fused epilogues)",
               9: "gemm_ws_kernel<3,3,O,O> (wave-specialised 192x192 wgrad dY^T X)"}
-PROFILE_TRAFFIC = "r02_pmc_traffic.json"
+PROFILE_TRAFFIC = "r03_pmc_traffic.json"
 
 
 def algorithmic_flops_per_video(sh):
@@ -395,16 +395,22 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS if slot >= 4 else 157.3      # slots 0-3 are the fp32 parity-mode kernels
             traffic, tsrc = None, None
-            try:                                   # HBM bytes per launch from the committed PMC passes
-                pj = os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)
+            try:                                   # HBM bytes per launch from the committed PMC passes, stamped with the
+                pj = os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)     # kernel sources they were taken with
                 pm = json.load(open(pj))
+                meta = pm.pop("_meta", {})
                 want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
-                        7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws_kernel<3, 3, true"}.get(slot)
-                hits = [v for k, v in pm.items() if want and want in k]
+                        7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws"}.get(slot)
+                hits = [v for k, v in pm.items() if want and want in k and (slot != 9 or "gemm_ws_kernel<3, 3, false" not in k)]
                 if hits:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    from profile_summary import csrc_sha16
+                    same = meta.get("csrc_sha16") == csrc_sha16()
                     tot = sum(h["launches"] for h in hits)
                     traffic = sum(h["hbm_bytes_per_launch_corrected"] * h["launches"] for h in hits) / tot
-                    tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)" % PROFILE_TRAFFIC
+                    tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH x2 gfx950 correction), "
+                            "taken with kernel sources %s = %s" % (PROFILE_TRAFFIC, meta.get("csrc_sha16"),
+                                                                  "the sources of this build" if same else "NOT this build's sources (stale)"))
             except Exception:
                 pass
             roof = {"bound": "mfma", "kernel": SLOT_NAMES.get(slot, "gemm slot %d" % slot),

@@ -1003,7 +1003,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned goa[G::PA], gob[G::PB];
     const char* pa = nullptr;
     const char* pb = nullptr;
-    unsigned ra_left = 0, rb_left = 0, sa = 0, sb = 0, fill = 0;
+    unsigned long long ra_left = 0, rb_left = 0;   // bytes to the end of the operand (64-bit: 1.4 M rows x 3072 columns at config 5)
+    unsigned sa = 0, sb = 0, fill = 0;
     auto setup = [&]() {
       const WsbItem it = g.items[(size_t)lr * nwg + wg];
       const WsbProb& P = g.p[it.prob];
@@ -1021,8 +1022,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int kb = it.k0 * 64;
       pa = reinterpret_cast<const char*>(P.A + (size_t)kb * P.lda + it.m0);
       pb = reinterpret_cast<const char*>(P.B + (size_t)kb * P.ldb + it.n0);
-      ra_left = (unsigned)(((size_t)(g.K - kb) * P.lda - it.m0) * 2);
-      rb_left = (unsigned)(((size_t)(g.K - kb) * P.ldb - it.n0) * 2);
+      ra_left = ((unsigned long long)(g.K - kb) * P.lda - it.m0) * 2;
+      rb_left = ((unsigned long long)(g.K - kb) * P.ldb - it.n0) * 2;
       sa = 64u * (unsigned)P.lda * 2u;
       sb = 64u * (unsigned)P.ldb * 2u;
     };
@@ -1030,8 +1031,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto issue = [&]() -> bool {
       if (lr >= g.rounds) return false;
       char* buf = smem + fill;
-      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, ra_left, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, rb_left, 0x00020000);
+      // the descriptor base moves with the k-step, so offsets stay small; only the range is clamped to 32 bits
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pa), 0, (unsigned)(ra_left < 0xfffffff0ull ? ra_left : 0xfffffff0ull), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pb), 0, (unsigned)(rb_left < 0xfffffff0ull ? rb_left : 0xfffffff0ull), 0x00020000);
 #ifndef HERO_WSB_NOLOADS        // lab ablations (tools/lab/build_variants.sh): results are garbage, timing only
 #pragma unroll
       for (int i = 0; i < G::PA; ++i)
@@ -1050,8 +1052,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (lr < g.rounds) setup();
       } else {
         pa += sa; pb += sb;
-        ra_left = ra_left > sa ? ra_left - sa : 0u;
-        rb_left = rb_left > sb ? rb_left - sb : 0u;
+        ra_left = ra_left > sa ? ra_left - sa : 0ull;
+        rb_left = rb_left > sb ? rb_left - sb : 0ull;
       }
       return true;
     };
@@ -1469,7 +1471,7 @@ extern "C" int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int
     const HeroWgradProblem& q = probs[i];
     HERO_REQUIRE(q.dy && q.x && q.dw && q.M > 0 && q.N > 0 && q.M % 8 == 0 && q.N % 8 == 0 && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 &&
                      q.ld_dw % 4 == 0 && (((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dw) & 15) == 0 &&
-                     (size_t)K * q.ld_dy * 2 < 0xffffffffull && (size_t)K * q.ld_x * 2 < 0xffffffffull &&
+                     (size_t)64 * q.ld_dy * 2 < 0x7fffffffull && (size_t)64 * q.ld_x * 2 < 0x7fffffffull &&
                      (size_t)q.M * q.ld_dw * 4 < 0x7ffffff0ull,
                  "hero_wgrad_batch: problem %d is unaligned / too large", i);
     WsbProb& P = g.p[i];

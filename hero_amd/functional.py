@@ -358,6 +358,8 @@ _WQ = []
 _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [os.environ.get("HERO_NOGROUP", "") == ""]      # HERO_NOGROUP=1: one launch per weight gradient (A/B runs)
 WGRAD_BATCH = [int(os.environ.get("HERO_WGRAD_BATCH", "32"))]   # 4: the per-layer stream-K launches of round 2
+WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5
+_WQ_BYTES = [0]                                                  # sizes its batch to 90 % of HBM: there it flushes at once)
 _WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) or None when the group is too small
 
 
@@ -440,6 +442,7 @@ def colsum_flush():
 
 
 def wgrad_flush():
+    _WQ_BYTES[0] = 0
     while _WQ:
         rows, dtype = _WQ[0][0].shape[0], _WQ[0][0].dtype
         n = 1
@@ -475,13 +478,15 @@ def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
         task = torch._C._current_graph_task_id()
         if _WQ and _WQ_TASK[0] != task:
             del _WQ[:]                  # left behind by a backward pass that raised: never launch them into this one
+            _WQ_BYTES[0] = 0
         if _WQ and (_WQ[0][0].shape[0] != M or _WQ[0][0].dtype != dy2.dtype):
             wgrad_flush()
         if not _WQ:
             _WQ_TASK[0] = task
         _ensure_flush_callback(task)
         _WQ.append((dy2, x2, out, col0, N, on_done))
-        if len(_WQ) >= _wgrad_limit():
+        _WQ_BYTES[0] += dy2.numel() * dy2.element_size()
+        if len(_WQ) >= _wgrad_limit() or _WQ_BYTES[0] > WGRAD_QUEUE_BYTES[0]:
             wgrad_flush()
         return out
     if out is None:

@@ -1,8 +1,21 @@
-# one gpurun call: the committed evidence of the round (profiles/r02_*)
+# one gpurun call: the committed evidence of the round (profiles/r03_*): kernel stats + PMC passes of the bench step,
+# kernel stats of the secondary workloads, the bench lines.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out; mkdir -p $OUT
-bash tools/profile_run.sh r02 > $OUT/r02_run.log 2>&1
-(timeout 600 python bench.py --steps 20 --warmup 4) > $OUT/r02_bench.json 2> $OUT/r02_bench.err
-for w in D2r D3; do (timeout 600 python bench.py --workload $w --steps 20 --warmup 4 2>/dev/null | grep "^{" | tail -1) > $OUT/r02_bench_$w.json; done
-(timeout 1500 python bench.py --workload D4 --steps 4 --warmup 2 2>/dev/null | grep "^{" | tail -1) > $OUT/r02_bench_D4.json
-tail -3 $OUT/r02_run.log; cut -c1-200 $OUT/r02_bench.json; for w in D2r D3 D4; do cut -c1-400 $OUT/r02_bench_$w.json | tail -c 260; echo; done
+TAG=${1:-r03}
+bash tools/profile_run.sh $TAG > $OUT/${TAG}_run.log 2>&1
+export TMPDIR=/tmp
+R=$PWD
+for w in D2r D3; do
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_$w -o s -- python $R/bench.py --workload $w --steps 4 --warmup 2 --no-graph > /dev/null 2> $R/$OUT/${TAG}_stats_$w.log)
+  # micro-steps in the trace: D2r 2 (prepare) + 2 (warm-up) + 4; D3: 4 tasks x (2 + 2 + 4)
+  python tools/profile_summary.py stats $OUT/${TAG}_stats_$w $([ $w = D3 ] && echo 32 || echo 8) $OUT/${TAG}_kernel_stats_$w.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload $w --steps 4 --warmup 2 --no-graph (MI355X)"
+  find $OUT/${TAG}_stats_$w -name "*kernel_trace.csv" -delete
+done
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_D4 -o s -- python $R/bench.py --workload D4 --videos 256 --steps 2 --warmup 2 > /dev/null 2> $R/$OUT/${TAG}_stats_D4.log)
+python tools/profile_summary.py stats $OUT/${TAG}_stats_D4 6 $OUT/${TAG}_kernel_stats_D4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload D4 --videos 256 --steps 2 --warmup 2 (MI355X; 256 videos x 256 frames per step)"
+find $OUT/${TAG}_stats_D4 -name "*kernel_trace.csv" -delete
+(timeout 600 python bench.py --steps 20 --warmup 4) > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+(timeout 600 python bench.py --steps 20 --warmup 4 --feed 4 --no-cpu-baseline | tail -1) > $OUT/${TAG}_bench_feed.json 2>> $OUT/${TAG}_bench.err
+tail -3 $OUT/${TAG}_run.log; cut -c1-200 $OUT/${TAG}_bench.json; cut -c1-200 $OUT/${TAG}_bench_feed.json
+for w in D2r D3 D4; do head -8 $OUT/${TAG}_kernel_stats_$w.csv | cut -c1-140; done

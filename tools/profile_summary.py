@@ -52,9 +52,22 @@ def _counter(d, name):
     return acc
 
 
+def csrc_sha16():
+    """Hash of the kernel sources the profile was taken with (bench.py stamps `roofline.traffic` with it)."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hero_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc(fd, wd, out):
     fe, wr = _counter(fd, "FETCH_SIZE"), _counter(wd, "WRITE_SIZE")
-    res = {}
+    res = {"_meta": {"csrc_sha16": csrc_sha16(), "note": "FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them, separate --pmc "
+                     "passes; hbm_bytes_per_launch_corrected = (2 x FETCH + WRITE) x 1024 (gfx950 counts 128-B reads as 64 B)"}}
     for k, (n, tot) in fe.items():
         if "hero::" not in k or k not in wr:
             continue

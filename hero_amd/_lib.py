@@ -55,7 +55,7 @@ DERIVE_MASK_ADD, DERIVE_F32, DERIVE_I32, DERIVE_FLAT_GATHER = 0, 1, 2, 3
 
 class WgradProblem(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
-                ("ld_dy", C.c_int), ("ld_x", C.c_int), ("ld_dw", C.c_int), ("split_hint", C.c_int)]
+                ("ld_dy", C.c_int), ("ld_x", C.c_int), ("ld_dw", C.c_int), ("split_hint", C.c_int), ("dbias", C.c_void_p)]
 
 
 class LnFwd(C.Structure):

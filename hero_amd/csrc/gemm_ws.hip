@@ -850,6 +850,7 @@ struct WsbProb {
   const bf16_t* A;      // dY [K, lda], M columns from the pointer on
   const bf16_t* B;      // X  [K, ldb], N columns
   float* C;             // dW [M, ldc]
+  float* colsum;        // optional [M]: += column sums of dY (bias gradient), from the tiles with n0 == 0
   int M, N, lda, ldb, ldc, pad_;
 };
 struct WsbItem { int prob, m0, n0, k0, nk, order, nslices, flag; };     // nk == 0: the slot is idle in this round
@@ -860,9 +861,12 @@ struct WsbArgs {
   WsbProb p[HERO_WGRAD_BATCH_MAX];
 };
 
+// want_cs (loader waves of a tile with n0 == 0 and a bias gradient): the four loader waves have left their column
+// partial sums of the dY panel in the spare LDS region ([4][BM] floats); loader wave 0 folds and applies them behind the
+// first pass barrier - inside the slice-order window, so the bias gradient is as reproducible as dW.
 template <typename G, bool COMPUTE>
 __device__ __forceinline__ void epilogue_acc(const WsbProb& P, const WsbItem& it, int* flags, char* smem, unsigned slot,
-                                             f32x16_t (*acc)[G::TN], int wave, int lane) {
+                                             f32x16_t (*acc)[G::TN], int wave, int lane, bool want_cs = false) {
   constexpr int TM = G::TM, TN = G::TN, BN = G::BN, RPP = G::RPP, C8 = G::C8, RPI = G::RPI, ITERS = G::ITERS;
   char* st = smem + slot;
   int tid = threadIdx.x;                             // opaque copy: see epilogue_rows
@@ -925,6 +929,16 @@ __device__ __forceinline__ void epilogue_acc(const WsbProb& P, const WsbItem& it
     }
     wait_lds();
     __builtin_amdgcn_s_barrier();                    // E1: the pass is staged
+    if constexpr (!COMPUTE) {
+      if (p == 0 && want_cs && tid - 256 < G::BM) {      // waves 4-6: one lane per column of the tile
+        const int c = tid - 256, gm = it.m0 + c;
+        const float* sp = reinterpret_cast<const float*>(smem + SPARE_OFF);
+        const float sum = (sp[c] + sp[G::BM + c]) + (sp[2 * G::BM + c] + sp[3 * G::BM + c]);
+        if (gm < P.M) {
+          if (plain) P.colsum[gm] += sum; else atomicAdd(P.colsum + gm, sum);
+        }
+      }
+    }
     if (plain) {
       // two iterations at a time (the staged values of all four would not fit beside 144 accumulators)
 #pragma unroll
@@ -1062,17 +1076,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (second) wait_vm<G::PW>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                                     // B(-1): stage 0 landed
     unsigned slot = 0;
+    // bias gradient on the side: the tiles of the first tile column (n0 == 0) stream every row of dY[:, m0 : m0 + 192]
+    // through the LDS anyway - the loader waves, idle between their DMA issues, add the rows of each landed stage up
+    // (wave w: k-rows 16 w .. 16 w + 15 of the stage; lanes 0-47: 16-byte chunk lane % 24 of rows 2 q + lane / 24)
+    const int cchunk = lane % 24, crr = lane / 24;
     for (int r = next_round(0); r < g.rounds; r = next_round(r + 1)) {
       const WsbItem it = g.items[(size_t)r * nwg + wg];
+      const bool want_cs = it.n0 == 0 && g.p[it.prob].colsum != nullptr;         // uniform
+      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int t = 0; t < it.nk; ++t) {
-        if (issue()) wait_vm<G::PW>(); else wait_vm<0>();
+        const bool more = issue();
+        if (want_cs && lane < 48) {
+          // stage `slot` (being consumed by the compute waves in this step) landed before the previous barrier; rows past
+          // the end of the reduction were zero-filled by the buffer descriptor
+          const char* sp = smem + slot;
+          u32x4_t v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int row = 16 * w + 2 * q + crr;
+            v[q] = *reinterpret_cast<const u32x4_t*>(sp + row * (G::BM * 2) + ((cchunk ^ swz_o<G::BM * 2>(row)) << 4));
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              cs[2 * e] += __uint_as_float(v[q][e] << 16);
+              cs[2 * e + 1] += __uint_as_float(v[q][e] & 0xffff0000u);
+            }
+        }
+        if (more) wait_vm<G::PW>(); else wait_vm<0>();
 #ifndef HERO_WSB_NOBAR
         __builtin_amdgcn_s_barrier();                                 // B(u)
 #endif
         if (t + 1 < it.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
       }
+      if (want_cs) {                                                    // fold the two row parities, park per wave
+        float* sp = reinterpret_cast<float*>(smem + SPARE_OFF) + w * G::BM;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float o = __shfl(cs[e], lane + 24, 64);
+          if (lane < 24) sp[cchunk * 8 + e] = cs[e] + o;
+        }
+      }
 #ifndef HERO_WSB_NOEPI
-      epilogue_acc<G, false>(g.p[it.prob], it, g.flags, smem, slot, nullptr, wave, lane);
+      epilogue_acc<G, false>(g.p[it.prob], it, g.flags, smem, slot, nullptr, wave, lane, want_cs);
 #endif
       slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0;
     }
@@ -1346,6 +1393,7 @@ extern "C" int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int
   for (int i = 0; i < n && ok; ++i) {
     const HeroWgradProblem& q = probs[i];
     HERO_REQUIRE(q.dy && q.x && q.dw && q.M > 0 && q.N > 0, "hero_wgrad_group: bad problem %d", i);
+    HERO_REQUIRE(q.dbias == nullptr, "hero_wgrad_group: dbias is a hero_wgrad_batch feature (problem %d)", i);
     ok = ok && q.M % 8 == 0 && q.N % 8 == 0 && q.ld_dy % 8 == 0 && q.ld_x % 8 == 0 && q.ld_dw % 4 == 0 &&
          (((uintptr_t)q.dy | (uintptr_t)q.x | (uintptr_t)q.dw) & 15) == 0 &&
          (size_t)K * q.ld_dy * 2 < 0xffffffffull && (size_t)K * q.ld_x * 2 < 0xffffffffull;
@@ -1477,6 +1525,7 @@ extern "C" int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int
     WsbProb& P = g.p[i];
     P.A = static_cast<const bf16_t*>(q.dy); P.B = static_cast<const bf16_t*>(q.x); P.C = q.dw;
     P.M = q.M; P.N = q.N; P.lda = q.ld_dy; P.ldb = q.ld_x; P.ldc = q.ld_dw; P.pad_ = 0;
+    P.colsum = q.dbias;
     flops += 2.0 * q.M * (double)q.N * K;
   }
   for (int i = n; i < HERO_WGRAD_BATCH_MAX; ++i) g.p[i] = g.p[0];

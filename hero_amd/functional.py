@@ -452,24 +452,38 @@ def wgrad_flush():
         del _WQ[:]
         _WQ.extend(rest)
         probs = (L.WgradProblem * n)()
-        for i, (dy2, x2, out, col0, N, _) in enumerate(group):
+        for i, (dy2, x2, out, col0, N, _, _, _) in enumerate(group):
             K = x2.shape[1]
             probs[i] = L.WgradProblem(L.ptr(dy2) + col0 * dy2.element_size(), L.ptr(x2), L.ptr(out), N, K,
-                                      dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32))
+                                      dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32), None)
         plan = _wgrad_plan(probs, n, rows, group[0][0].device) if dtype == torch.bfloat16 else None
         if plan is not None:
+            ride = os.environ.get("HERO_WGRAD_DBIAS", "1") != "0"       # 0: separate (deferred) column sums, for A/B runs
+            for i, e in enumerate(group):                   # bias gradients ride on the dY panels of the batch kernel
+                probs[i].dbias = L.ptr(e[6]) if ride else None
+                if not ride and e[6] is not None:
+                    k_colsum(e[0], out=e[6], beta=1.0, col0=e[3], ncols=e[4], on_done=lambda: None)
             L.check(L.lib().hero_wgrad_batch(probs, n, rows, L.BF16, L.ptr(plan[0]), plan[1], L.stream()))
+            for e in group:
+                if e[6] is not None and e[7] is not None:
+                    e[7]()
         else:
             for g0 in range(0, n, 4):
                 sub = (L.WgradProblem * min(4, n - g0))(*[probs[i] for i in range(g0, min(g0 + 4, n))])
                 L.check(L.lib().hero_wgrad_group(sub, len(sub), rows, L.dt(group[0][0]), L.stream()))
+            for dy2, _, _, col0, N, _, dbias, dbias_done in group:
+                if dbias is not None:
+                    k_colsum(dy2, out=dbias, beta=1.0, col0=col0, ncols=N, on_done=dbias_done or (lambda: None))
         for e in group:
             if e[5] is not None:
                 e[5]()
 
 
-def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
-    """dW[N,K] (fp32) = beta*dW + dy2[:, col0:col0+N]^T @ x2[M,K]."""
+def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None, dbias=None, dbias_done=None):
+    """dW[N,K] (fp32) = beta*dW + dy2[:, col0:col0+N]^T @ x2[M,K].
+    dbias ([N] fp32, accumulated): the bias gradient of the same layer = column sums of the same dY columns.  When the
+    problem goes out through hero_wgrad_batch they are taken from the dY panels that kernel streams anyway; otherwise
+    they become a (deferred) hero_colsum of their own."""
     M, ld = dy2.shape
     N = ld - col0 if ncols is None else ncols
     K = x2.shape[1]
@@ -484,11 +498,13 @@ def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
         if not _WQ:
             _WQ_TASK[0] = task
         _ensure_flush_callback(task)
-        _WQ.append((dy2, x2, out, col0, N, on_done))
+        _WQ.append((dy2, x2, out, col0, N, on_done, dbias, dbias_done))
         _WQ_BYTES[0] += dy2.numel() * dy2.element_size()
         if len(_WQ) >= _wgrad_limit() or _WQ_BYTES[0] > WGRAD_QUEUE_BYTES[0]:
             wgrad_flush()
         return out
+    if dbias is not None:
+        k_colsum(dy2, out=dbias, beta=1.0, col0=col0, ncols=N, on_done=dbias_done or (lambda: None))
     if out is None:
         out = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
     split = _split_for(N, K, M, 64 if dy2.dtype == torch.bfloat16 else 32)
@@ -533,9 +549,11 @@ def k_colsum(dy2, out=None, beta=0.0, col0=0, ncols=None, on_done=None):
 def acc_linear_grads(dy2, x2, weight, bias, col0=0, ncols=None):
     """weight.grad += dy^T x ; bias.grad += colsum(dy) straight into the gradient sink."""
     N = ncols if ncols is not None else weight.shape[0]
+    want_b = bias is not None and bias.requires_grad
     if weight is not None and weight.requires_grad:
-        k_wgrad(dy2, x2, out=SINK.dst(weight), beta=1.0, col0=col0, ncols=N, on_done=lambda: SINK.done(weight))
-    if bias is not None and bias.requires_grad:
+        k_wgrad(dy2, x2, out=SINK.dst(weight), beta=1.0, col0=col0, ncols=N, on_done=lambda: SINK.done(weight),
+                dbias=SINK.dst(bias) if want_b else None, dbias_done=(lambda: SINK.done(bias)) if want_b else None)
+    elif want_b:
         k_colsum(dy2, out=SINK.dst(bias), beta=1.0, col0=col0, ncols=N, on_done=lambda: SINK.done(bias))
 
 
@@ -1003,8 +1021,9 @@ def _qkv_bwd(dqkv, x2, qkv_params, D):
     gw = SINK.dst_group(ws) if all(p.requires_grad for p in ws) else None
     gb = SINK.dst_group(bs) if all(p.requires_grad for p in bs) else None
     if gw is not None:
-        k_wgrad(dqkv, x2, out=gw, beta=1.0, on_done=lambda: [SINK.done(p) for p in ws])
-    if gb is not None:
+        k_wgrad(dqkv, x2, out=gw, beta=1.0, on_done=lambda: [SINK.done(p) for p in ws],
+                dbias=gb.view(-1) if gb is not None else None, dbias_done=lambda: [SINK.done(p) for p in bs])
+    elif gb is not None:
         k_colsum(dqkv, out=gb.view(-1), beta=1.0, on_done=lambda: [SINK.done(p) for p in bs])
     for i, (w, b) in enumerate(zip(ws, bs)):
         acc_linear_grads(dqkv, x2, None if gw is not None else w, None if gb is not None else b, col0=i * D,

@@ -98,6 +98,8 @@ typedef struct HeroWgradProblem {
   float* dw;        /* [M, ld_dw] fp32, accumulated                            */
   int M, N, ld_dy, ld_x, ld_dw;
   int split_hint;
+  float* dbias;     /* optional [M] fp32 (hero_wgrad_batch only; must be NULL for hero_wgrad_group): += column sums of */
+                    /* dy = the bias gradient of the same nn.Linear, taken from the dY panels the kernel streams anyway */
 } HeroWgradProblem;
 int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int dtype, hero_stream_t stream);
 /* Batched weight gradients, whole tiles: up to HERO_WGRAD_BATCH_MAX problems over the same K rows - the weight

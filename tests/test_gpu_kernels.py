@@ -234,7 +234,15 @@ def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
     dys, xs, outs, probs = _batch_problems(Lb, rows, layers, shapes)
     n = len(dys)
+    # bias gradients from the dY panels the kernel streams (every problem but the first, which checks the NULL case)
+    dbs = [torch.full((o.shape[0],), 0.125, device="cuda") for o in outs]
+    for i in range(1, n):
+        probs[i].dbias = dbs[i].data_ptr()
     plan = _run_batch(Lb, probs, n, rows)
+    for i in range(1, n):
+        torch.testing.assert_close(dbs[i], dys[i].float().sum(0) + 0.125, rtol=1e-4, atol=2e-4 * rows)
+    assert float((dbs[0] - 0.125).abs().max()) == 0.0
+    first_db = [d.clone() for d in dbs]
     assert plan[6] == layers * 192
     if rows != 12000:
         assert plan[7] > 1                      # the tail round is sliced
@@ -245,9 +253,13 @@ def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     for rep in range(2):
         for o in outs:
             o.fill_(0.25)
+        for d in dbs:
+            d.fill_(0.125)
         _run_batch(Lb, probs, n, rows)
         for o, f in zip(outs, first):
             assert torch.equal(o, f), "hero_wgrad_batch is not bit-reproducible"
+        for d, f in zip(dbs, first_db):
+            assert torch.equal(d, f), "hero_wgrad_batch bias gradients are not bit-reproducible"
     # the slice-order flags are back to zero: a second launch right behind the first one accumulates once more
     _run_batch(Lb, probs, n, rows)
     for i in (0, n - 1):

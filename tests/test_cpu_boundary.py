@@ -42,7 +42,8 @@ def test_struct_layouts_match_header_sizes(built_lib):
     src = '#include <stdio.h>\n#include "hero_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(HeroDropout),sizeof(HeroGemmEpilogue),sizeof(HeroLnFwd),sizeof(HeroLnBwd),' \
           'sizeof(HeroAttn),sizeof(HeroAdamW));printf("%zu %zu %zu\\n",sizeof(HeroTensorDesc),' \
-          'sizeof(HeroAdamWGroup),sizeof(HeroAdamWMulti));printf("%zu\\n",sizeof(HeroCrossEntropy));return 0;}\n'
+          'sizeof(HeroAdamWGroup),sizeof(HeroAdamWMulti));printf("%zu %zu %zu %zu\\n",sizeof(HeroCrossEntropy),' \
+          'sizeof(HeroWgradProblem),sizeof(HeroColsum),sizeof(HeroDerive));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "s.c"), "w") as f:
             f.write(src)
@@ -51,8 +52,20 @@ def test_struct_layouts_match_header_sizes(built_lib):
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
     mine = [ctypes.sizeof(c) for c in (_lib.Dropout, _lib.GemmEpilogue, _lib.LnFwd, _lib.LnBwd,
                                        _lib.Attn, _lib.AdamW, _lib.TensorDesc, _lib.AdamWGroup,
-                                       _lib.AdamWMulti, _lib.CrossEntropy)]
+                                       _lib.AdamWMulti, _lib.CrossEntropy, _lib.WgradProblem, _lib.Colsum, _lib.Derive)]
     assert mine == sizes
+    # field offsets of the structs that changed in round 3
+    for cls, cname in ((_lib.WgradProblem, "HeroWgradProblem"), (_lib.Colsum, "HeroColsum"), (_lib.Derive, "HeroDerive"),
+                       (_lib.LnBwd, "HeroLnBwd")):
+        fields = [f for f, _ in cls._fields_]
+        src = '#include <stdio.h>\n#include <stddef.h>\n#include "hero_hip.h"\nint main(){%s return 0;}\n' % "".join(
+            'printf("%%zu ", offsetof(%s, %s));' % (cname, f) for f in fields)
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "o.c"), "w") as f:
+                f.write(src)
+            subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "o.c"), "-o", os.path.join(d, "o")])
+            offs = list(map(int, subprocess.check_output([os.path.join(d, "o")]).split()))
+        assert [getattr(cls, f).offset for f in fields] == offs, cname
 
 
 def test_integration_md_ctypes_snippet_matches_header():

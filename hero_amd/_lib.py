@@ -109,7 +109,7 @@ class AdamWMulti(C.Structure):
     _fields_ = [("descs", C.c_void_p), ("chunk_tensor", C.c_void_p), ("chunk_index", C.c_void_p),
                 ("n_chunks", C.c_int), ("groups", AdamWGroup * 8), ("step", C.c_int),
                 ("grad_sumsq", C.c_void_p), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float),
-                ("step_ptr", C.c_void_p), ("lr_ptr", C.c_void_p)]
+                ("step_ptr", C.c_void_p), ("lr_ptr", C.c_void_p), ("tensor_steps", C.c_void_p), ("n_tensors", C.c_int)]
 
 
 class CopyDesc(C.Structure):

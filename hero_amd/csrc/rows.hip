@@ -264,6 +264,10 @@ __global__ void adamw_kernel(HeroAdamW a, float bc1, float bc2) {
 // One launch over many tensors (descriptor tables live in device memory, one block per 16K-element
 // chunk).  Same arithmetic as adamw_kernel.
 constexpr int MT_CHUNK = 16384;
+__global__ void adamw_steps_inc_kernel(const HeroTensorDesc* descs, int n, int32_t* steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) steps[descs[i].step_lag] += 1;            // slots are distinct per tensor
+}
 __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
   const int ti = a.chunk_tensor[blockIdx.x];
   const HeroTensorDesc d = a.descs[ti];
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
     const float clip = a.max_grad_norm / (norm + 1e-6f);
     if (clip < 1.f) gs *= clip;
   }
-  const float st = (float)((a.step_ptr ? *a.step_ptr : a.step) - d.step_lag);
+  const float st = a.tensor_steps ? (float)a.tensor_steps[d.step_lag] : (float)((a.step_ptr ? *a.step_ptr : a.step) - d.step_lag);
   const float lr = a.lr_ptr ? a.lr_ptr[d.group] : gr.lr;
   const float bc1 = 1.f - powf(gr.beta1, st), bc2 = 1.f - powf(gr.beta2, st);
   const float step_size = lr * sqrtf(bc2) / bc1;
@@ -472,8 +476,15 @@ extern "C" int hero_adamw(const HeroAdamW* a, hero_stream_t stream) {
 
 extern "C" int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream) {
   HERO_REQUIRE(a && a->descs && a->chunk_tensor && a->chunk_index, "hero_adamw_multi: null pointer");
-  HERO_REQUIRE(a->step >= 1 || a->step_ptr, "hero_adamw_multi: step must be >= 1");
+  HERO_REQUIRE(a->step >= 1 || a->step_ptr || a->tensor_steps, "hero_adamw_multi: step must be >= 1");
   if (a->n_chunks <= 0) return HERO_OK;
+  if (a->tensor_steps) {
+    HERO_REQUIRE(a->n_tensors > 0, "hero_adamw_multi: tensor_steps needs n_tensors");
+    hipLaunchKernelGGL(adamw_steps_inc_kernel, dim3((a->n_tensors + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a->descs,
+                       a->n_tensors, a->tensor_steps);
+    const int rc = check_launch("hero_adamw_multi(steps)");
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(a->n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("hero_adamw_multi");
 }

@@ -91,6 +91,11 @@ def _d(drop):
 # --------------------------------------------------------------------------------------------- #
 _WCACHE = {}
 _WEPOCH = [0]
+_WGEN = [0]            # grows with every NEW compute copy: a captured refresh_weight_cache() covers the copies of its time only
+
+
+def weight_cache_generation():
+    return _WGEN[0]
 
 
 def notify_weights_updated():
@@ -100,6 +105,7 @@ def notify_weights_updated():
 
 
 def clear_weight_cache():
+    _WGEN[0] += 1
     _WCACHE.clear()
     _REFRESH["sig"] = _REFRESH["tables"] = None
 
@@ -189,6 +195,8 @@ def packed(params, dtype):
         L.check(L.lib().hero_cast(L.ptr(p.detach().contiguous()), dst.data_ptr(), n, L.F32,
                                   L.dt(out), L.stream()))
         off += p.shape[0]
+    if hit is None:
+        _WGEN[0] += 1
     _WCACHE[key] = (sig, out, params)
     return out
 
@@ -214,6 +222,8 @@ def packed_t(params, dtype):
                                             out.data_ptr() + off * out.element_size(), p.shape[0], kin,
                                             cols, L.dt(out), L.stream()))
         off += p.shape[0]
+    if hit is None:
+        _WGEN[0] += 1
     _WCACHE[key] = (sig, out, params)
     return out
 

@@ -28,16 +28,20 @@ class AdamW(Optimizer):
         self._global_step = 0
         self._tables = {}         # signature -> (device tensors, n_chunks)
         self._pinned = []         # tables built or used while a hipGraph was capturing: the graph holds their addresses
+        self._tsteps = None       # device-state mode: per-parameter step counts on the device (int32 [n params])
+        self._slots = None        # parameter -> slot in _tsteps
 
     def load_state_dict(self, state_dict):
         """A restore replaces the moment tensors the descriptor tables point at: drop the tables (the ones captured
         graphs use stay alive in `_pinned`, but such graphs must be re-captured - TrainStep refuses the restore)."""
         super().load_state_dict(state_dict)
         self._tables = {}
+        self._tsteps = None       # re-seeded from the restored state['step'] at the next device-state step
 
     def __setstate__(self, state):
         super().__setstate__(state)
         self._tables, self._pinned = {}, []
+        self._tsteps = self._slots = None
 
     # ---- gradient norm ---------------------------------------------------------------------------
     def grad_sumsq(self, flat=None):
@@ -58,7 +62,26 @@ class AdamW(Optimizer):
         return out
 
     # ---- descriptor table ------------------------------------------------------------------------
-    def _build_table(self, active):
+    def _device_steps(self, dev):
+        """Per-parameter step counts on the device (seeded from the host-side state['step'])."""
+        if self._tsteps is None:
+            params = [p for g in self.param_groups for p in g["params"]]
+            self._slots = {p: i for i, p in enumerate(params)}
+            host = [int(self.state[p].get("step", 0)) if p in self.state else 0 for p in params]
+            self._tsteps = torch.tensor(host, dtype=torch.int32, device=dev)
+        return self._tsteps
+
+    def sync_steps_from_device(self):
+        """Bring state['step'] up to the device-side counters (hipGraph replays advance only those)."""
+        if self._tsteps is None:
+            return
+        host = self._tsteps.cpu().tolist()
+        for p, i in self._slots.items():
+            if p in self.state and "step" in self.state[p]:
+                self.state[p]["step"] = host[i]
+        self._global_step = max([self._global_step] + host)
+
+    def _build_table(self, active, slots=False):
         chunk = L.lib().hero_adamw_multi_chunk()
         descs = (L.TensorDesc * len(active))()
         ct, ci = [], []
@@ -68,7 +91,7 @@ class AdamW(Optimizer):
             if not (p.is_contiguous() and g.is_contiguous()):
                 raise RuntimeError("hero_amd AdamW needs contiguous parameters and gradients")
             descs[i] = L.TensorDesc(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                    p.numel(), gi, self._global_step - st["step"])
+                                    p.numel(), gi, self._slots[p] if slots else self._global_step - st["step"])
             n = -(-p.numel() // chunk)
             ct.extend([i] * n)
             ci.extend(range(n))
@@ -84,7 +107,12 @@ class AdamW(Optimizer):
         """step_tensor (int32[1]) / lr_tensor (float32[8]) on the device override the host-side step
         count and per-group learning rates — required when the step is captured in a hipGraph."""
         loss = closure() if closure is not None else None
-        self._global_step += 1
+        device_state = step_tensor is not None
+        if not device_state:
+            if self._tsteps is not None:                 # back from device-state mode: the device counters are the truth
+                self.sync_steps_from_device()
+                self._tsteps = None
+            self._global_step += 1
         active = []
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
@@ -95,17 +123,26 @@ class AdamW(Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
+                if not device_state:
+                    st["step"] += 1
                 active.append((gi, p))
         if not active:
             return loss
-        sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
-                     self.state[p]["exp_avg_sq"].data_ptr(), self._global_step - self.state[p]["step"]) for _, p in active)
+        tsteps = self._device_steps(active[0][1].device) if device_state else None
+        if device_state:
+            # per-parameter counts live on the device and are advanced by the kernel for the ACTIVE parameters only:
+            # graphs of other tasks never touch the counters of parameters they skip (the reference's state['step'],
+            # optim/adamw.py:71-72)
+            sig = ("dev",) + tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                                    self.state[p]["exp_avg_sq"].data_ptr(), self._slots[p]) for _, p in active)
+        else:
+            sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                         self.state[p]["exp_avg_sq"].data_ptr(), self._global_step - self.state[p]["step"]) for _, p in active)
         capturing = torch.cuda.is_current_stream_capturing()
         if sig not in self._tables:
             if len(self._tables) >= 16 and not capturing:
                 self._tables = {}                 # eager multi-task runs change the signature often; pinned tables survive
-            self._tables[sig] = self._build_table(active)
+            self._tables[sig] = self._build_table(active, slots=device_state)
         if capturing and not any(t is self._tables[sig] for t in self._pinned):
             self._pinned.append(self._tables[sig])
         raw, t_ct, t_ci, n_chunks = self._tables[sig]
@@ -114,8 +151,9 @@ class AdamW(Optimizer):
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             a.groups[gi] = L.AdamWGroup(group["lr"], b1, b2, group["eps"], group["weight_decay"])
-        a.step = self._global_step
+        a.step = max(self._global_step, 1)
         a.step_ptr, a.lr_ptr = L.ptr(step_tensor), L.ptr(lr_tensor)
+        a.tensor_steps, a.n_tensors = L.ptr(tsteps), len(active)
         a.grad_sumsq = L.ptr(grad_sumsq)
         a.max_grad_norm, a.grad_scale = max_grad_norm, grad_scale
         L.check(L.lib().hero_adamw_multi(C.byref(a), L.stream()))

@@ -157,6 +157,13 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.micro += 2 * accum
+        self._record(batch, task)
+
+    def _record(self, batch, task):
+        """Capture the two graphs of `task` (every lazy state exists already).  Also used to RE-capture a task whose
+        graphs are older than the newest compute copy of a weight: the captured weight-copy refresh covers the copies
+        that existed at capture time only, so a task captured later (the tied MLM decoder copy, a head's weights)
+        would otherwise read stale copies of weights this task's optimiser step changes."""
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread queries events of earlier collectives: only THIS thread's
         # calls may invalidate the capture
@@ -169,6 +176,8 @@ class TrainStep:
             loss_b = self._fwd_bwd(batch, task)
             self._optimise(device_state=True)
         self._graphs[task] = (ga, loss_a, gb, loss_b, batch)
+        self._graph_gen = getattr(self, "_graph_gen", {})
+        self._graph_gen[task] = HF.weight_cache_generation()
 
     def prepare(self, batch, task=None):
         """One-time setup outside any timed region: in graph mode the eager warm-up micro-steps and the
@@ -190,6 +199,10 @@ class TrainStep:
         of one accumulation window must be of the same task."""
         if task not in self._graphs:
             self._capture(batch, task)
+        accum = self.opts.gradient_accumulation_steps
+        if self.micro % accum == 0 and self._graph_gen[task] != HF.weight_cache_generation():
+            torch.cuda.synchronize()                 # window start: re-capture against the current set of weight copies
+            self._record(self._graphs[task][4], task)
         ga, loss_a, gb, loss_b, static_batch = self._graphs[task]
         if batch is not static_batch:
             raise RuntimeError("graph mode replays the captured batch buffers (and the index / mask tensors derived "
@@ -212,14 +225,9 @@ class TrainStep:
 
     # ---- checkpointing ---------------------------------------------------------------------------------
     def _sync_optimizer_steps(self):
-        """hipGraph replays advance the optimiser step on the device only; bring the host-side counters
-        (bias-correction steps in optimizer.state) up to date before they are saved."""
-        delta = self.global_step - self.optimizer._global_step
-        if delta > 0:
-            self.optimizer._global_step += delta
-            for st in self.optimizer.state.values():
-                if "step" in st:
-                    st["step"] += delta
+        """hipGraph replays advance the optimiser's per-parameter step counts on the device only; bring the host-side
+        counters (bias-correction steps in optimizer.state) up to date before they are saved."""
+        self.optimizer.sync_steps_from_device()
 
     def state_dict(self):
         self._sync_optimizer_steps()

@@ -306,6 +306,13 @@ typedef struct HeroAdamWMulti {
   float grad_scale;
   const int32_t* step_ptr; /* optional device scalar overriding `step` (hipGraph replays)      */
   const float* lr_ptr;     /* optional device array [8] overriding groups[].lr                 */
+  int32_t* tensor_steps;   /* optional device array of PER-TENSOR step counts (round 3): a tensor's count lives  */
+                           /* in slot descs[i].step_lag, is incremented by this call (a pre-pass over the        */
+                           /* n_tensors descriptors) and is the step of its bias correction - the reference's    */
+                           /* state['step'], which only advances when the parameter is updated                   */
+                           /* (optim/adamw.py:71-72), kept on the device so that captured graphs of different    */
+                           /* tasks do not advance the counters of parameters they skip                          */
+  int n_tensors;           /* number of descriptors (needed with tensor_steps)                                   */
 } HeroAdamWMulti;
 int hero_adamw_multi(const HeroAdamWMulti* a, hero_stream_t stream);
 int hero_adamw_multi_chunk(void);

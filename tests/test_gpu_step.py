@@ -151,3 +151,62 @@ def test_checkpoint_restore_after_steps_matches_uninterrupted_run():
         HF.set_grad_sink(None)
         HF.clear_weight_cache()
         hero_amd.set_compute_dtype(torch.bfloat16)
+
+
+def test_multi_task_graph_replay_keeps_per_parameter_adam_steps():
+    """in graph mode the Adam bias-correction step of a parameter that only ONE task updates must advance
+    only in that task's optimiser steps (the reference's state['step'], optim/adamw.py:71-72).  Per-parameter counters
+    live on the device and are advanced by the captured AdamW launch for its active parameters only: a two-task run
+    (vsm / mlm windows interleaved) replayed from per-task graphs ends with the parameters of the eager run."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.model import HeroForPretraining
+    from hero_amd.model.layers import BertEncoder
+    from hero_amd.step import TrainStep
+    from hero_amd.utils.misc import set_dropout
+    from tests.test_oracle_golden import _task_batches
+    hero_amd.set_compute_dtype(torch.float32)
+    pre, _ = O.load_npz_case(os.path.join(GOLDEN, "case_pretrain.npz"))
+    mlm, _, _ = _task_batches(pre)
+    vsm, _ = O.load_npz_case(os.path.join(GOLDEN, "case_train.npz"))
+    batches = {"mlm": to_dev(mlm, "cuda"), "vsm": to_dev(vsm, "cuda")}
+    windows = ["vsm", "mlm", "mlm", "vsm", "mlm"]
+
+    def run(use_graph):
+        HF.set_grad_sink(None)
+        HF.clear_weight_cache()
+        model, _, _ = load_tiny("cuda", cls=HeroForPretraining)
+        model.train()
+        set_dropout(model, 0.0)
+        ts = TrainStep(model, opts=dict(learning_rate=1e-3, warmup_steps=2, num_train_steps=100), task="vsm", use_graph=use_graph)
+        if use_graph:                                      # capture both tasks first (each capture runs 2 warm-up windows)
+            for t in ("vsm", "mlm"):
+                ts.prepare(batches[t], t)
+        else:
+            for t in ("vsm", "mlm"):
+                for _ in range(4):
+                    ts.micro_step(batches[t], t)
+        for t in windows:
+            for _ in range(2):
+                ts.micro_step(batches[t], t)
+        torch.cuda.synchronize()
+        sd = ts.state_dict()
+        steps = {n: ts.optimizer.state[p]["step"] for n, p in model.named_parameters() if p in ts.optimizer.state and "step" in ts.optimizer.state[p]}
+        HF.set_grad_sink(None)
+        return {k: v.detach().clone() for k, v in model.named_parameters()}, steps, sd
+
+    BertEncoder.allow_packing = False
+    try:
+        pe, se, _ = run(False)
+        pg, sg, _ = run(True)
+    finally:
+        BertEncoder.allow_packing = True
+        HF.clear_weight_cache()
+        hero_amd.set_compute_dtype(torch.bfloat16)
+    only_mlm = "v_encoder.f_encoder.lm_head.dense.weight"
+    only_vsm = "video_query_linear.weight"
+    both = "v_encoder.f_encoder.encoder.layer.0.attention.self.query.weight"
+    assert se[only_mlm] == 2 + 3 and se[only_vsm] == 2 + 2 and se[both] == 4 + 5       # warm-up windows + the run's
+    assert sg == se, {k: (sg[k], se[k]) for k in se if sg.get(k) != se[k]}
+    for k in (only_mlm, only_vsm, both):
+        assert rel_err(pg[k], pe[k]) < 5e-4, (k, rel_err(pg[k], pe[k]))

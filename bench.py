@@ -468,6 +468,8 @@ def main():
         timer.daemon = True
         timer.start()
         try:
+            while trainer.micro % trainer.opts.gradient_accumulation_steps:     # odd --steps / --warmup: finish the window
+                step()
             trainer.enable_graph(collectives=True)
             dt_g, loss_g = timed_run()
             if dt_g < dt and loss_g == loss_g:

@@ -314,3 +314,31 @@ def _negatives(rank, world):
 
 def test_gather_negatives_slice_backward():
     assert all(spawn(_negatives))
+
+
+def _negatives_uniform(rank, world):
+    """UNIFORM_SHAPES: every rank feeds the same padded shape, so the per-forward size exchange is skipped - the gather
+    and its slice backward must equal the exchanging path's."""
+    from hero_amd.utils import distributed as D
+    torch.manual_seed(rank)
+    q = torch.randn(3, 4, requires_grad=True)
+    c = torch.randn(3, 5, 4, requires_grad=True)
+    m = (torch.rand(3, 5) > 0.3).long()
+    res = []
+    for uniform in (False, True):
+        D.UNIFORM_SHAPES[0] = uniform
+        try:
+            Q, Cx, M, own = D.gather_negatives(q, c, m, return_own=True)
+        finally:
+            D.UNIFORM_SHAPES[0] = False
+        q.grad = c.grad = None
+        w = torch.arange(6.0).view(6, 1)
+        ((Q * w).sum() + (Cx * w.view(6, 1, 1)).sum()).backward()
+        res.append((Q.detach().clone(), Cx.detach().clone(), M.clone(), own, q.grad.clone(), c.grad.clone()))
+    a, b = res
+    ok = all(torch.equal(x, y) for x, y in zip(a[:3] + a[4:], b[:3] + b[4:])) and a[3] == b[3] == (3 * rank, 3)
+    return bool(ok)
+
+
+def test_gather_negatives_uniform_shapes_skips_the_size_exchange():
+    assert all(spawn(_negatives_uniform))

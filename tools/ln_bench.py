@@ -6,12 +6,24 @@ import torch
 from hero_amd import functional as HF
 
 
+_RAMPED = [False]
+
+
 def timeit(fn, n=40, warm=3):
-    """kernel time: n calls captured in one hipGraph (no host gaps), replayed 5 times"""
+    """kernel time: n calls captured in one hipGraph (no host gaps), replayed 5 times.  The first ~70 ms of matrix work
+    after idle run up to 20 % slower (clock ramp, tools/lab/warm_probe.py: 58.6 -> 48.4 us for the same GEMM), so the first
+    call in a process keeps the GPU busy for 0.2 s before anything is timed."""
+    import time
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         for _ in range(warm): fn()
         torch.cuda.synchronize()
+        if not _RAMPED[0]:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.2:
+                for _ in range(10): fn()
+                torch.cuda.synchronize()
+            _RAMPED[0] = True
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
             for _ in range(n): fn()

@@ -26,7 +26,7 @@ int main() {
   float* d; long long* c; hipMalloc(&d, 256 * 512 * 4); hipMalloc(&c, 8);
   for (int threads : {256, 512}) {
     const int iters = 2000;
-    hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, 10, c);
+    for (int w = 0; w < 300; ++w) hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, 2000, c);   // ~0.3 s: past the clock ramp
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);

@@ -885,18 +885,20 @@ def cross_entropy(logits, labels, ncols=None, ignore_index=-100, inv_temp=1.0):
 
 class EmbedLnFn(torch.autograd.Function):
     """y = dropout(LN(x + sum_k table_k[idx_k])) — embedding sums of model/embed.py fused with their
-    LayerNorm.  idx_k None = row 0 of the given (fp32) table slice for every row.  Gradients of
-    leaf tables are scatter-added straight into the gradient sink (no dense temporary)."""
+    LayerNorm.  idx_k None = row 0 of the given (fp32) table for every row, an int = that fixed row
+    (the token-type row: slicing the parameter instead would cost a zeros + copy + add in autograd).
+    Gradients of leaf tables are scatter-added straight into the gradient sink (no dense temporary)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, drop, out_dtype, skip_idx, idxs, *tables):
         x2 = _as2d(x) if x is not None else None
         cols = gamma.shape[0]
         rows = x2.shape[0] if x2 is not None else idxs[0].numel()
-        tabs = [t.detach() for t in tables]
+        tabs = [t.detach()[i:i + 1] if isinstance(i, int) else t.detach()
+                for t, i in zip(tables, tuple(idxs) + (None,) * len(tables))]
         y, mean, rstd, pre = k_ln_fwd(x2, gamma.detach(), beta.detach(), eps, out_dtype, rows, cols,
-                                      tabs=tabs, idxs=idxs, want_pre=len(tables) > 0, drop=drop,
-                                      device=gamma.device)
+                                      tabs=tabs, idxs=[None if isinstance(i, int) else i for i in idxs],
+                                      want_pre=len(tables) > 0, drop=drop, device=gamma.device)
         ctx.drop, ctx.idxs, ctx.skip = drop, idxs, skip_idx
         ctx.tables = tables
         ctx.ln = (gamma, beta)
@@ -927,10 +929,11 @@ class EmbedLnFn(torch.autograd.Function):
         for k, tab in enumerate(ctx.tables):
             idx = ctx.idxs[k] if k < len(ctx.idxs) else None
             skip = ctx.skip[k] if ctx.skip else -1
+            row, idx = (idx, None) if isinstance(idx, int) else (0, idx)
             if _is_param(tab):
                 per = getattr(idx, "_hero_period", 0) if idx is not None else 0
                 if idx is None:
-                    k_colsum(dx, out=SINK.dst(tab).view(-1, tab.shape[-1])[0], beta=1.0, on_done=lambda tab=tab: SINK.done(tab))
+                    k_colsum(dx, out=SINK.dst(tab).view(-1, tab.shape[-1])[row], beta=1.0, on_done=lambda tab=tab: SINK.done(tab))
                     grads_t.append(None)
                     continue
                 elif per and dx.shape[0] % per == 0 and dx.shape[0] // per >= 8:
@@ -947,7 +950,7 @@ class EmbedLnFn(torch.autograd.Function):
             else:
                 g = torch.zeros(tab.shape, dtype=torch.float32, device=dy.device)
                 if idx is None:
-                    k_colsum(dx, out=g.view(-1, tab.shape[-1])[0])
+                    k_colsum(dx, out=g.view(-1, tab.shape[-1])[row])
                 else:
                     k_scatter_add(dx, idx, g, None, skip)
                 grads_t.append(g)
@@ -957,6 +960,46 @@ class EmbedLnFn(torch.autograd.Function):
 
 def embed_ln(x, gamma, beta, eps, drop, out_dtype, tables=(), idxs=(), skip_idx=None):
     return EmbedLnFn.apply(x, gamma, beta, eps, drop, out_dtype, skip_idx, tuple(idxs), *tables)
+
+
+class StackRowsFn(torch.autograd.Function):
+    """cat of 2-D row blocks; the backward hands out views of dy (aten's CatBackward does too, this one exists for
+    symmetry with SplitRowsFn and to keep the pair out of the dispatcher)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.rows = [x.shape[0] for x in xs]
+        return torch.cat(xs, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        out, r0 = [], 0
+        for i, n in enumerate(ctx.rows):
+            out.append(dy[r0:r0 + n] if ctx.needs_input_grad[i] else None)
+            r0 += n
+        return tuple(out)
+
+
+class SplitRowsFn(torch.autograd.Function):
+    """x -> row blocks of the given sizes (views).  backward = ONE cat of the block gradients; aten's slices would
+    each materialise a zero tensor of the full shape, copy their block in and add the results (5 passes over the
+    stacked rows instead of 1: 64 us per micro-step on the sub + query stack of the bench batch)."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.sizes, ctx.meta = sizes, (x.shape[1], x.dtype, x.device)
+        outs, r0 = [], 0
+        for n in sizes:
+            outs.append(x[r0:r0 + n])
+            r0 += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cols, dtype, dev = ctx.meta
+        parts = [g.reshape(n, cols) if g is not None else torch.zeros((n, cols), dtype=dtype, device=dev)
+                 for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
 
 
 class GatherRowsFn(torch.autograd.Function):

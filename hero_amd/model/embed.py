@@ -54,7 +54,7 @@ class SubEmbeddings(nn.Module):
         wid = _row_index(input_ids, S, Lt)
         pid = _row_index(position_ids, S, Lt)
         if token_type_ids is None:
-            type_tab, tid, type_row = self.token_type_embeddings.weight[1:2], None, 1
+            type_tab, tid, type_row = self.token_type_embeddings.weight, 1, 1            # fixed row 1 of the table
         else:
             type_tab, tid, type_row = self.token_type_embeddings.weight, _row_index(token_type_ids, S, Lt), 0
         y = HF.embed_ln(None, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
@@ -91,12 +91,15 @@ class ImageEmbeddings(nn.Module):
         else:
             normed = HF.embed_ln(img_feat, self.img_LayerNorm.weight, self.img_LayerNorm.bias, 1e-5, None, cd)
         t = HF.linear(normed.view(S * Lv, Dv), self.img_linear.weight, self.img_linear.bias)
-        if type_embeddings.numel() != t.shape[1]:
+        if isinstance(type_embeddings, tuple):                    # (table parameter, fixed row): no autograd slice
+            type_tab, type_idx = type_embeddings
+        elif type_embeddings.numel() != t.shape[1]:
             raise NotImplementedError("per-token img_type_ids are not used by HERO (a single type row is)")
-        type_tab = type_embeddings.reshape(1, -1)
+        else:
+            type_tab, type_idx = type_embeddings.reshape(1, -1), None
         y = HF.embed_ln(t, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
                         _drop(self.dropout, img_feat.device), cd,
-                        tables=(self.position_embeddings.weight, type_tab), idxs=(pid, None))
+                        tables=(self.position_embeddings.weight, type_tab), idxs=(pid, type_idx))
         return y.view(S, Lv, -1)
 
 

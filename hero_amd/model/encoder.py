@@ -116,7 +116,7 @@ class CrossModalTrm(RobertaPreTrainedModel):
         self.vocab_pad = n_pad
 
     def _type_row(self):
-        return self.embeddings.token_type_embeddings.weight[1:2]
+        return (self.embeddings.token_type_embeddings.weight, 1)     # fixed row of the table (see EmbedLnFn)
 
     def _compute_txt_embeddings(self, input_ids, position_ids, txt_type_ids=None):
         return self.embeddings(input_ids=input_ids, position_ids=position_ids,

@@ -292,7 +292,7 @@ class BertEncoder(nn.Module):
         xs = [HF.cast(h, cd) for h in hidden_list]
         segs = tuple((x.shape[0], x.shape[1]) for x in xs)
         D = xs[0].shape[-1]
-        x = torch.cat([t.reshape(-1, D) for t in xs], 0) if len(xs) > 1 else xs[0].reshape(-1, D)
+        x = HF.StackRowsFn.apply(*[t.reshape(-1, D) for t in xs]) if len(xs) > 1 else xs[0].reshape(-1, D)
         plan = None
         if self.pack_ragged and BertEncoder.allow_packing and all(m is not None for m in mask_list) and x.is_cuda:
             plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs],
@@ -307,11 +307,10 @@ class BertEncoder(nn.Module):
         masks = tuple(HF.as_mask_add(m, s[0], s[1]) for m, s in zip(mask_list, segs))
         for layer in self.layer:
             x = layer.forward_rows(x, segs, masks)
-        outs, r0 = [], 0
-        for (S, Lq) in segs:
-            outs.append(x[r0:r0 + S * Lq].view(S, Lq, D))
-            r0 += S * Lq
-        return outs
+        if len(segs) == 1:
+            return [x.view(segs[0][0], segs[0][1], D)]
+        blocks = HF.SplitRowsFn.apply(x, *[S * Lq for (S, Lq) in segs])
+        return [b.view(S, Lq, D) for b, (S, Lq) in zip(blocks, segs)]
 
 
 class BertLMPredictionHead(nn.Module):

@@ -142,10 +142,17 @@ struct GeluFast {
 };
 template <typename T> __device__ __forceinline__ float gelu_fwd(float x);
 template <> __device__ __forceinline__ float gelu_fwd<float>(float x) { return gelu_erf(x); }
+#ifdef HERO_GELU_ABLATE        // lab only (tools/lab/build_variants.sh): what the GELU arithmetic costs in the epilogues
+template <> __device__ __forceinline__ float gelu_fwd<bf16_t>(float x) { return x * 0.5f; }
+#else
 template <> __device__ __forceinline__ float gelu_fwd<bf16_t>(float x) { return x * GeluFast(x).cdf; }
+#endif
 template <typename T> __device__ __forceinline__ float gelu_grad(float x);
 template <> __device__ __forceinline__ float gelu_grad<float>(float x) { return gelu_erf_grad(x); }
 template <> __device__ __forceinline__ float gelu_grad<bf16_t>(float x) {
+#ifdef HERO_GELU_ABLATE
+  return 0.5f;
+#endif
   const GeluFast g(x);
   return fmaf(x * 0.39894228040143267794f, g.q, g.cdf);
 }

@@ -1251,6 +1251,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   template __global__ void gemm_ws_kernel<TM, TN, false, EK_GELU_BWD>(WsArgs);                \
   template __global__ void gemm_ws_kernel<TM, TN, true, 0>(WsArgs);
 HERO_WS_INST(3, 3)
+HERO_WS_INST(2, 3)
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1311,18 +1312,19 @@ static int launch_kk(const WsArgs& g, hipStream_t s) {
 }  // namespace ws
 
 // Problems this family takes: bf16, K,K operands with one of the six hot-path epilogues, or the O,O
-// wgrad accumulate; large enough to fill the chip with 192 x 192 tiles.  force_cfg: -1 heuristic,
-// 8 never, 9 always (when the shape is legal).
+// wgrad accumulate; large enough to fill the chip with 192 x 192 (or, under one round, 128 x 192) tiles.
+// force_cfg: -1 heuristic, 8 never, 9 always 192 x 192, 10 always 128 x 192 (when the shape is legal).
 int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_layout,
                 int b_layout, const HeroGemmEpilogue& epi, int force_cfg, hipStream_t s) {
   using namespace ws;
   if (force_cfg == 8) return -1;
-  if (force_cfg != 9 && force_cfg != -1) return -1;      // a forced 4-wave geometry
+  if (force_cfg != 9 && force_cfg != 10 && force_cfg != -1) return -1;      // a forced 4-wave geometry
   typedef Geo<3, 3> G;
   const bool kk = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
   const bool oo = a_layout == HERO_LAYOUT_O && b_layout == HERO_LAYOUT_O;
   if (!kk && !oo) return -1;
   if (K < 64 || N % 8 != 0 || M < 8) return -1;
+  if (force_cfg == 10 && !kk) return -1;
   WsArgs g;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -1334,12 +1336,22 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
   if (kk) {
     if (K % 64 != 0 || epi.out_f32 || epi.split_k > 1) return -1;
     if ((size_t)M * lda * 2 >= 0x7fffffffull || (size_t)N * ldb * 2 >= 0x7fffffffull || (size_t)M * ldc >= 0x7fffffffull) return -1;
-    // worth it from about half a round of tiles; below that the 4-wave 64 x 64 / 128 x 128 tiles fill the chip better
-    if (force_cfg != 9 && ntile * 2 < cus) return -1;
     g.nsplit = 1;
     g.k_per_split = K;
+    g.group = 8;
+    // Under one round of 192 x 192 tiles the launch lasts as long as ONE tile: 128 x 192 tiles (Geo<2, 3>) are
+    // shorter and use more of the CUs (M = 1920, N = 3072: 240 instead of 160 tiles; N = 2304: 180 instead of 120).
+    typedef Geo<2, 3> G2;
+    const int t23 = ((M + G2::BM - 1) / G2::BM) * g.tiles_n;
+    const bool small = force_cfg == 10 || (force_cfg == -1 && ntile * 5 < cus * 4 && t23 <= cus && t23 * 5 >= cus * 2);
+    if (small) {
+      g.tiles_m = (M + G2::BM - 1) / G2::BM;
+      g.nwork = t23;
+      return launch_kk<2, 3>(g, s);
+    }
+    // worth it from about half a round of tiles; below that the 4-wave 64 x 64 / 128 x 128 tiles fill the chip better
+    if (force_cfg != 9 && ntile * 2 < cus) return -1;
     g.nwork = ntile;
-    g.group = N >= 2560 ? 8 : 8;
     return launch_kk<3, 3>(g, s);
   }
   // O,O: fp32 accumulate, reduction split so that the items fill the CUs

@@ -112,6 +112,17 @@ def test_gemm_wave_specialised_matches_4wave_kernels(HF, Lb, M, N, K):
     """gemm_ws.hip (persistent 192x192 tiles, loader / compute waves) against the 4-wave kernels and the fp32
     reference: the six fused epilogues, the SAME dropout mask (index m*N + n), row / column tails, several
     tiles per workgroup (24000 x 3072: 2000 tiles on 256 CUs)."""
+    _ws_against_4wave(HF, Lb, M, N, K, 9)
+
+
+@pytest.mark.parametrize("M,N,K", [(1920, 3072, 768), (1920, 2304, 768), (1000, 200, 128), (385, 192, 64), (5000, 3072, 768)])
+def test_gemm_wave_specialised_128x192_tiles(HF, Lb, M, N, K):
+    """The 128 x 192 geometry of the same kernel (Geo<2, 3>: four 32-row epilogue passes), which the 1920-row GEMMs of
+    the Temporal Transformer take; row / column tails and more than one tile per workgroup (5000 x 3072: 640 tiles)."""
+    _ws_against_4wave(HF, Lb, M, N, K, 10)
+
+
+def _ws_against_4wave(HF, Lb, M, N, K, ws_cfg):
     dtype = torch.bfloat16
     x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
     res, u = rnd(M, N, dtype=dtype, seed=4), rnd(M, N, dtype=dtype, seed=6)
@@ -132,7 +143,7 @@ def test_gemm_wave_specialised_matches_4wave_kernels(HF, Lb, M, N, K):
         finally:
             Lb.lib().hero_gemm_force_config(-1)
 
-    got, old = run(9, 0), run(8, 1)
+    got, old = run(ws_cfg, 0), run(8, 1)
     ref = x.float() @ w.float().t()
     sc = math.sqrt(K) * 0.05
     close(got[0], ref + b, dtype, scale=sc)

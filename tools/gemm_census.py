@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Census of the GEMM launches of one bench micro-step: every (shape, layouts, epilogue) hero_gemm sees, how often,
 and the time of each distinct one under the default geometry choice and under forced geometries
-(hero_gemm_force_config 0..3 = the 4-wave tiles, 9 = wave-specialised 192 x 192 where legal).
+(hero_gemm_force_config 0..3 = the 4-wave tiles, 9 / 10 = wave-specialised 192 x 192 / 128 x 192 where legal).
 
     python tools/gemm_census.py [max_M]      # only shapes with M <= max_M are timed under forced geometries
 """
@@ -80,7 +80,7 @@ def bench_one(key, cfg, reps=30):
 
 
 LAY = {L.LAYOUT_K: "K", L.LAYOUT_O: "O"}
-print("%6s %6s %6s  lay dt  epilogue                      calls   default  " % ("M", "N", "K") + "  ".join("cfg%d" % c for c in (0, 1, 2, 3, 9)))
+print("%6s %6s %6s  lay dt  epilogue                      calls   default  " % ("M", "N", "K") + "  ".join("cfg%d" % c for c in (0, 1, 2, 3, 9, 10)))
 tot = collections.Counter()
 for key, n in seen.items():
     M, N, K, al, bl, dt, hb, hr, ha, act, of32, beta, split, hd, hc = key
@@ -89,12 +89,12 @@ for key, n in seen.items():
     t0 = bench_one(key, -1)
     forced = []
     if M <= max_m and not of32:
-        for c in (0, 1, 2, 3, 9):
+        for c in (0, 1, 2, 3, 9, 10):
             t = bench_one(key, c)
             forced.append("%6.1f" % t if t is not None else "     -")
     gf = 2.0 * M * N * K / 1e9
     print("%6d %6d %6d  %s,%s %s  %-28s %5d  %7.1f us %5.0f TF/s  %s" % (M, N, K, LAY[al], LAY[bl], "bf" if dt == L.BF16 else "f32", epi, n, t0,
-                                                                      gf / t0 * 1e-3 if t0 else 0, " ".join(forced)))
+                                                                      gf / t0 * 1e3 if t0 else 0, " ".join(forced)))
     tot["all"] += n * t0
     if M <= max_m:
         tot["small"] += n * t0

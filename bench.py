@@ -40,7 +40,8 @@ SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (4-wave tiles, K-contiguous operands: t
               5: "gemm_kernel<bf16,K,O>", 7: "gemm_glds_tr_kernel (bf16 wgrad dY^T X, 128x128 tiles)", 6: "gemm_kernel<bf16,O,K>",
               8: "gemm_ws_kernel<3,3,K,K> (wave-specialised persistent 192x192 tiles: forward x W^T and dgrad dY (W^T)^T "
                  "of the M = 12000 row batch, fused epilogues)",
-              9: "gemm_ws_kernel<3,3,O,O> (wave-specialised 192x192 wgrad dY^T X)"}
+              9: "gemm_ws_kernel<3,3,O,O> (wave-specialised 192x192 wgrad dY^T X)",
+              10: "gemm_ws_kernel<2,3,K,K> (wave-specialised 128x192 tiles: the 1920-row GEMMs with N >= 2304)"}
 PROFILE_TRAFFIC = "r03_pmc_traffic.json"
 
 
@@ -384,7 +385,7 @@ def main():
             trainer.micro_step(batch)
         torch.cuda.synchronize()
         best = None
-        for slot in range(10):
+        for slot in range(11):
             ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
             L.check(L.lib().hero_prof_read(slot, C.byref(ms), C.byref(fl), C.byref(n)))
             if n.value and (best is None or ms.value > best[1]):
@@ -400,8 +401,9 @@ def main():
                 pm = json.load(open(pj))
                 meta = pm.pop("_meta", {})
                 want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
-                        7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws"}.get(slot)
-                hits = [v for k, v in pm.items() if want and want in k and (slot != 9 or "gemm_ws_kernel<3, 3, false" not in k)]
+                        7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws",
+                        10: "gemm_ws_kernel<2, 3, false"}.get(slot)
+                hits = [v for k, v in pm.items() if want and want in k and (slot != 9 or ", false," not in k)]
                 if hits:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     from profile_summary import csrc_sha16

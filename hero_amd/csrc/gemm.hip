@@ -776,7 +776,7 @@ struct ProfSlot {
   std::vector<hipEvent_t> ev;  // start/stop pairs
   std::vector<double> flops;
 };
-static ProfSlot g_prof[10];   // 0-7: (dtype, layouts) of the 4-wave kernels; 8 / 9: wave-specialised K,K / O,O kernels
+static ProfSlot g_prof[11];   // 0-7: (dtype, layouts) of the 4-wave kernels; 8 / 9: wave-specialised 192 x 192 K,K / O,O kernels; 10: 128 x 192 K,K
 static bool g_prof_on = false;
 static int g_force_cfg = -1;   // tuning hook: force a geometry (0,1,2,3), 8 / 9: wave-specialised kernels never / always; -1 = heuristic
 
@@ -785,7 +785,7 @@ int gemm_forced_config() { return g_force_cfg; }
 struct ProfToken { ProfSlot* ps; hipEvent_t e0; };
 void* gemm_prof_begin(int slot, hipStream_t s) {
   if (!g_prof_on) return nullptr;
-  ProfSlot* ps = &g_prof[slot < 10 ? slot : 0];
+  ProfSlot* ps = &g_prof[slot < 11 ? slot : 0];
   hipEvent_t e0 = nullptr;
   if (ps->flops.size() >= 16384 || hipEventCreate(&e0) != hipSuccess) return nullptr;
   (void)hipEventRecord(e0, s);
@@ -1073,7 +1073,7 @@ extern "C" int hero_prof_enable(int on) {
   return HERO_OK;
 }
 extern "C" int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches) {
-  HERO_REQUIRE(slot >= 0 && slot < 10 && total_ms && total_flops && launches, "hero_prof_read: bad arguments");
+  HERO_REQUIRE(slot >= 0 && slot < 11 && total_ms && total_flops && launches, "hero_prof_read: bad arguments");
   ProfSlot& p = g_prof[slot];
   double ms = 0.0, fl = 0.0;
   for (size_t i = 0; i < p.flops.size(); ++i) {

@@ -1300,12 +1300,12 @@ static int launch_kk(const WsArgs& g, hipStream_t s) {
   const HeroGemmEpilogue& e = g.epi;
   const bool b = e.bias != nullptr, r = e.residual != nullptr, d = e.dropout.threshold16 != 0;
   if (e.colsum != nullptr && e.act != HERO_ACT_GELU_BWD) return -1;     // column sums exist in the gelu' epilogue only: 4-wave path
-  if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, 8, s);
-  if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, 8, s);
-  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, 8, s);
-  if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, 8, s);
-  if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, 8, s);
-  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, 8, s);
+  if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, TM == 3 ? 8 : 10, s);
+  if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, TM == 3 ? 8 : 10, s);
+  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, TM == 3 ? 8 : 10, s);
+  if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, TM == 3 ? 8 : 10, s);
+  if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, TM == 3 ? 8 : 10, s);
+  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, TM == 3 ? 8 : 10, s);
   return -1;
 }
 

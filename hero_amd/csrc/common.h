@@ -46,37 +46,61 @@ template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p =
 template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
 // ---- counter-based dropout -------------------------------------------------------------------
-// One splitmix64 draw yields four 16-bit uniforms = the keep decisions of 4 consecutive elements.
-// The same (seed word, site, group index) is replayed by the backward kernels, so no mask is stored.
+// The keep decisions of 4 consecutive elements (a "group") are four 16-bit uniforms: two 32-bit hashes of the group
+// index, keyed by the two halves of splitmix64(seed word ^ site).  The same (seed word, site, group index) is replayed
+// by the backward kernels, so no mask is stored.
+// The per-group hash is mix32 (C. Wellons' "lowbias32": xorshift-multiply x 2, avalanche bias 0.17) - 4 quarter-rate
+// 32-bit multiplies per group.  Rounds 1-2 drew the 64 bits from splitmix64(base + group * C): three 64 x 64-bit
+// multiplies = 12 quarter-rate multiplies + 64-bit shifts per group.  The 32-bit form has ~40 % fewer VALU slots per draw
+// and the step did not notice (6.63 vs 6.61 ms): what the masks cost in the kernels (-DHERO_DROP_ABLATE, rocprofv3 A/B:
+// 0.06 ms per micro-step - LayerNorm backward 1.2 us per launch, the dropout GEMM epilogue 2.2 us, attention 0.7-1 us)
+// is the index / compare / select work around the draw, not its multiplies.
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  return x ^ (x >> 16);
+}
 struct DropCtx {
-  uint64_t base;
+  uint32_t k0, k1;
   uint32_t thr;
   float scale;
   __device__ __forceinline__ DropCtx(const HeroDropout& d) {
     thr = d.threshold16;
     scale = d.scale;
-    base = thr ? splitmix64((d.seed_ptr ? *d.seed_ptr : 0ull) ^ (d.site * 0xD6E8FEB86659FD93ull)) : 0ull;
+    const uint64_t base = thr ? splitmix64((d.seed_ptr ? *d.seed_ptr : 0ull) ^ (d.site * 0xD6E8FEB86659FD93ull)) : 0ull;
+    k0 = (uint32_t)base;
+    k1 = (uint32_t)(base >> 32);
   }
   __device__ __forceinline__ bool on() const { return thr != 0; }
+  // group index -> 32-bit hash input (the high word, zero below 2^34 elements, is folded in with a full-rate 24-bit multiply)
+  __device__ __forceinline__ uint32_t fold(uint64_t group) const {
+    return (uint32_t)group ^ __umul24((uint32_t)(group >> 32), 0xC2B2AEu);
+  }
   // group = index of a 4-element group; returns per-element multipliers (0 or scale)
   __device__ __forceinline__ float4 mask4(uint64_t group) const {
-    uint64_t r = splitmix64(base + group * 0x9E3779B97F4A7C15ull);
+#ifdef HERO_DROP_ABLATE       // lab only: what the hash costs (keeps everything)
+    return make_float4(scale, scale, scale, scale);
+#endif
+    const uint32_t g = fold(group);
+    const uint32_t r0 = mix32(g ^ k0), r1 = mix32(g ^ k1);
     float4 m;
-    m.x = ((uint32_t)(r & 0xffff) >= thr) ? scale : 0.f;
-    m.y = ((uint32_t)((r >> 16) & 0xffff) >= thr) ? scale : 0.f;
-    m.z = ((uint32_t)((r >> 32) & 0xffff) >= thr) ? scale : 0.f;
-    m.w = ((uint32_t)(r >> 48) >= thr) ? scale : 0.f;
+    m.x = ((r0 & 0xffffu) >= thr) ? scale : 0.f;
+    m.y = ((r0 >> 16) >= thr) ? scale : 0.f;
+    m.z = ((r1 & 0xffffu) >= thr) ? scale : 0.f;
+    m.w = ((r1 >> 16) >= thr) ? scale : 0.f;
     return m;
   }
   __device__ __forceinline__ float mask1(uint64_t elem) const {
-    uint64_t r = splitmix64(base + (elem >> 2) * 0x9E3779B97F4A7C15ull);
-    return ((uint32_t)((r >> (16 * (elem & 3))) & 0xffff) >= thr) ? scale : 0.f;
+    const uint32_t r = mix32(fold(elem >> 2) ^ ((elem & 2) ? k1 : k0));
+    return (((r >> (16 * (uint32_t)(elem & 1))) & 0xffffu) >= thr) ? scale : 0.f;
   }
 };
 

@@ -576,6 +576,38 @@ def test_ln_bwd_dropout_consistency(HF, Lb):
     torch.testing.assert_close(dbias, 3 + dxd.sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("p_drop", [0.1, 0.3])
+def test_dropout_mask_statistics(HF, Lb, p_drop):
+    """The counter-based mask (csrc/common.h DropCtx: two keyed 32-bit hashes per 4-element group): keep rate within
+    5 sigma of 1 - p, no correlation between neighbours along a row, down a column or between the four elements of a
+    group, a different mask per site, the same mask when a site is replayed."""
+    M, N, K = 2048, 768, 64
+    x, w, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, N, seed=4)
+    masks = []
+    for _ in range(2):
+        drop = HF.RNG.make(p_drop, True, x.device)
+        y = HF.k_linear(x, w, None, residual=res, drop=drop)
+        y2 = HF.k_linear(x, w, None, residual=res, drop=drop)
+        torch.testing.assert_close(y, y2, rtol=0, atol=0)                   # same site + seed word: same mask
+        masks.append(((y - res).abs() > 1e-7).double())
+    m = masks[0]
+    n = m.numel()
+    sigma = math.sqrt(p_drop * (1 - p_drop) / n)
+    assert abs(m.mean().item() - (1 - p_drop)) < 5 * sigma + 1.0 / 65536      # the threshold is a 16-bit fraction
+
+    def corr(a, b):
+        a, b = a.reshape(-1) - a.mean(), b.reshape(-1) - b.mean()
+        return (a * b).mean().item() / math.sqrt((a * a).mean().item() * (b * b).mean().item())
+    lim = 6.0 / math.sqrt(n)
+    assert abs(corr(m[:, :-1], m[:, 1:])) < lim                               # along a row (inside and across groups)
+    assert abs(corr(m[:-1], m[1:])) < lim                                     # down a column
+    g4 = m.reshape(M, N // 4, 4)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(corr(g4[..., i], g4[..., j])) < lim                    # the four decisions of one hash pair
+    assert abs(corr(masks[0], masks[1])) < lim                                # another site: another mask
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gather_scatter(HF, dtype):
     a, b = rnd(50, 128, dtype=dtype, seed=1), rnd(30, 128, dtype=dtype, seed=2)

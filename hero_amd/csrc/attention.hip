@@ -600,8 +600,14 @@ static int check_attn(const HeroAttn* a, bool bwd) {
   HERO_REQUIRE(a->dtype == HERO_F32 || a->dtype == HERO_BF16, "hero_attention: bad dtype %d", a->dtype);
   HERO_REQUIRE(!a->seq_off || a->L <= (a->dtype == HERO_BF16 ? 256 : 64), "hero_attention: packed batches (seq_off) need L <= %d, got %d",
                a->dtype == HERO_BF16 ? 256 : 64, a->L);
-  if (bwd) HERO_REQUIRE(a->probs && a->dctx && a->dqkv, "hero_attention_bwd: probs/dctx/dqkv required");
-  else HERO_REQUIRE(a->ctx, "hero_attention_fwd: ctx required");
+  if (bwd) {
+    HERO_REQUIRE((a->probs || a->stats) && a->dctx && a->dqkv, "hero_attention_bwd: probs (or stats)/dctx/dqkv required");
+    if (!a->probs)
+      HERO_REQUIRE(hero_attention_stats_ok(a->dtype, a->L), "hero_attention_bwd: dtype %d, L = %d needs the saved probabilities (stats alone: bf16, L <= 64)",
+                   a->dtype, a->L);
+  } else {
+    HERO_REQUIRE(a->ctx, "hero_attention_fwd: ctx required");
+  }
   return HERO_OK;
 }
 
@@ -619,6 +625,7 @@ extern "C" int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   return a->dtype == HERO_BF16 ? run<bf16_t>(*a, true, s) : run<float>(*a, true, s);
 }
+extern "C" int hero_attention_stats_ok(int dtype, int L) { return dtype == HERO_BF16 && L >= 1 && L <= 64 && use_mfma() ? 1 : 0; }
 extern "C" int hero_attention_max_packed_len(int dtype) { return dtype == HERO_BF16 && use_mfma() ? 256 : 64; }
 extern "C" int hero_attention_max_len(int dtype, int backward) {
   if (dtype == HERO_BF16 && use_mfma()) return 256;       // matrix-core kernels (the backward wants a.ctx beyond 64)

@@ -139,6 +139,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
       }
     sum += xhalf(sum);
     const float inv = 1.f / sum;
+    if (a.stats && half == 0 && i < L)                 // what the backward needs to rebuild this row of P from q, k
+      *reinterpret_cast<float2*>(a.stats + ((size_t)(s * a.H + h) * Lm + i) * 2) = make_float2(mx, inv);
     float* prow = a.probs ? a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm : nullptr;
     const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, cx, lane);
 }
 
-template <int NB, int WPB>
+template <int NB, int WPB, bool RC>       // RC: no saved probabilities - rebuilt from q, k and the saved row statistics
 __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = 32 * NB;
@@ -230,6 +232,34 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
       }
     }
   }
+  // Without saved probabilities: S^T = K Q^T again, from the staged tiles - the same MFMAs on the same operands as the
+  // forward's, then the same scale / mask / exp / normalise with the saved row maximum and 1 / row sum: bit-identical P.
+  constexpr bool recompute = RC;
+  f32x16_t sc[RC ? NB : 1][RC ? NB : 1];
+  float mk[RC ? NB : 1][16];
+  if constexpr (RC) {
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      bf16x8_t qf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = lfrag(Qs, 32 * it + l31, ks, half);
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[jt][it][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          sc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lfrag(Ks, 32 * jt + l31, ks, half), qf[ks], sc[jt][it], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * jt + acc_row(r, half);
+        mk[jt][r] = a.mask ? a.mask[(size_t)s * Lm + min(j, L - 1)] : 0.f;
+      }
+  }
   // K^T fragments for dQ (same key <-> k-slot assignment as the forward's V^T)
   bf16x8_t kf[2][NB][2];
 #pragma unroll
@@ -248,7 +278,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
     const int i = 32 * it + l31;
-    const float* prow = a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm;
+    const float* prow = recompute ? nullptr : a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm;
     const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
     float pr[NB][16], ds[NB][16];
     // The saved probabilities of this lane's 16 accumulator slots are 4 runs of 4 consecutive columns: four 16-byte
@@ -256,7 +286,18 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
     // `(i < L && j < L) ? prow[j] : 0` the compiler sank each of the 16 scalar loads into its own conditional block,
     // each followed by s_waitcnt vmcnt(0): 16 serial round trips per 32-row block.
     const float rowok = i < L ? 1.f : 0.f;
-    if ((Lm & 3) == 0) {
+    if constexpr (RC) {
+      const float2 st = *reinterpret_cast<const float2*>(a.stats + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * 2);
+#pragma unroll
+      for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * jt + acc_row(r, half);
+          const float v = j < L ? fmaf(sc[jt][it][r], a.scale, mk[jt][r]) : -3.0e38f;
+          const float e = j < L ? __expf(v - st.x) : 0.f;
+          pr[jt][r] = e * st.y * rowok;
+        }
+    } else if ((Lm & 3) == 0) {
 #pragma unroll
       for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
@@ -364,10 +405,12 @@ int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
     const size_t lds = (size_t)WPB * (3 * R * RS * 2 + 2 * R * (R + 8) * 2);
     static bool set = false;
     if (!set && lds > 65536) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       set = true;
     }
-    hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true>), dim3(grid), dim3(64 * WPB), lds, s, a);
   } else {
     const size_t lds = (size_t)WPB * R * RS * 2;
     hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB>), dim3(grid), dim3(64 * WPB), lds, s, a);

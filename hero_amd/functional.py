@@ -635,24 +635,37 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
     return dx, (dxd if dxd is not None else dx), dg, db
 
 
+ATTN_SAVE_PROBS = os.environ.get("HERO_ATTN_SAVE_PROBS", "0") == "1"     # A/B switch: keep the fp32 probabilities for the backward
+
+
 def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None, seq_off=None):
     """seq_off (int32 [S+1]): packed batch - sequence s is rows [seq_off[s], seq_off[s+1]) of qkv,
-    Lq is the maximum length (<= 64; bf16: <= 256)."""
+    Lq is the maximum length (<= 64; bf16: <= 256).
+    Returns (ctx, saved): `saved` is what k_attn_bwd needs - the fp32 probabilities [S, H, Lq, Lq], or, where the
+    kernels can rebuild them (hero_attention_stats_ok: bf16, Lq <= 64), the softmax row statistics as a FLAT fp32
+    tensor [S*H*Lq*2] (13.8 MB -> 1.2 MB per layer on the bench batch)."""
     D = H * 64
     ctx = out if out is not None else torch.empty((qkv.shape[0], D), dtype=qkv.dtype, device=qkv.device)
-    probs = torch.empty((S, H, Lq, Lq), dtype=torch.float32, device=qkv.device) if want_probs else None
+    probs = stats = None
+    if want_probs:
+        if not ATTN_SAVE_PROBS and L.lib().hero_attention_stats_ok(L.dt(qkv), Lq):
+            stats = torch.empty((S * H * Lq * 2,), dtype=torch.float32, device=qkv.device)
+        else:
+            probs = torch.empty((S, H, Lq, Lq), dtype=torch.float32, device=qkv.device)
     a = L.Attn(L.ptr(qkv), L.ptr(mask_add), L.ptr(ctx), L.ptr(probs), None, None, S, Lq, H,
-               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off))
+               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off), L.ptr(stats))
     L.check(L.lib().hero_attention_fwd(C.byref(a), L.stream()))
-    return ctx, probs
+    return ctx, (stats if stats is not None else probs)
 
 
-def k_attn_bwd(qkv, probs, dctx, S, Lq, H, drop=None, out=None, seq_off=None, ctx=None):
-    """ctx: the forward output (optional).  With it the bf16 backward of 64 < Lq <= 256 runs on the
-    matrix-core kernels (delta_i = dO_i . ctx_i); without it those lengths take the fp32-VALU path."""
+def k_attn_bwd(qkv, saved, dctx, S, Lq, H, drop=None, out=None, seq_off=None, ctx=None, mask_add=None):
+    """saved: k_attn_fwd's second result.  ctx: the forward output (optional).  With it the bf16 backward of
+    64 < Lq <= 256 runs on the matrix-core kernels (delta_i = dO_i . ctx_i); without it those lengths take the
+    fp32-VALU path.  mask_add: the forward's additive mask - needed when `saved` holds row statistics."""
     dqkv = out if out is not None else torch.empty_like(qkv)
-    a = L.Attn(L.ptr(qkv), None, L.ptr(ctx), L.ptr(probs), L.ptr(dctx), L.ptr(dqkv), S, Lq, H,
-               1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off))
+    is_stats = saved.dim() == 1
+    a = L.Attn(L.ptr(qkv), L.ptr(mask_add) if is_stats else None, L.ptr(ctx), None if is_stats else L.ptr(saved), L.ptr(dctx),
+               L.ptr(dqkv), S, Lq, H, 1.0 / math.sqrt(64.0), L.dt(qkv), _d(drop), L.ptr(seq_off), L.ptr(saved) if is_stats else None)
     L.check(L.lib().hero_attention_bwd(C.byref(a), L.stream()))
     return dqkv
 
@@ -1094,7 +1107,7 @@ class SelfAttentionFn(torch.autograd.Function):
         bqkv = packed((bq, bk, bv), torch.float32)
         qkv = k_linear(x2, Wqkv, bqkv)
         ctxt, probs = k_attn_fwd(qkv, mask_add, S, Lq, H, drop=drop_p)
-        ctx.dims, ctx.drop = (S, Lq, H, D), drop_p
+        ctx.dims, ctx.drop, ctx.mask_add = (S, Lq, H, D), drop_p, mask_add
         ctx.params = (wq, bq, wk, bk, wv, bv)
         _use(*ctx.params)
         ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), qkv, probs, ctxt)
@@ -1104,7 +1117,7 @@ class SelfAttentionFn(torch.autograd.Function):
     def backward(ctx, dctx):
         x2, Wqkv_t, qkv, probs, ctxt = ctx.saved_tensors
         S, Lq, H, D = ctx.dims
-        dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop, ctx=ctxt)
+        dqkv = k_attn_bwd(qkv, probs, _as2d(dctx), S, Lq, H, drop=ctx.drop, ctx=ctxt, mask_add=ctx.mask_add)
         dx = k_dgrad_t(dqkv, Wqkv_t).view(S, Lq, D) if ctx.needs_input_grad[0] else None
         _qkv_bwd(dqkv, x2, ctx.params, D)
         return (dx,) + (None,) * 9
@@ -1175,6 +1188,7 @@ class AttnBlockFn(torch.autograd.Function):
         y1 = k_linear(ctxt, Wo, bo.detach(), residual=x2, drop=drop_hid)
         a, mean, rstd, _ = k_ln_fwd(y1, g1.detach(), b1.detach(), eps, y1.dtype, x2.shape[0], D)
         ctx.meta = (segs, H, D, drops_attn, drop_hid, x.shape)
+        ctx.masks = masks                 # additive masks (derived, no grad): the backward rebuilds P from q, k with them
         ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1)
         _use(*ctx.params)
         ctx.save_for_backward(x2, packed_t((wq, wk, wv), x2.dtype), packed_t((wo,), x2.dtype), qkv, ctxt, y1,
@@ -1199,14 +1213,14 @@ class AttnBlockFn(torch.autograd.Function):
         dctx = k_dgrad_t(dy1d, Wo_t)
         dqkv = torch.empty_like(qkv)
         r0 = 0
-        for seg, p, dr in zip(segs, probs, drops_attn):
+        for seg, p, dr, m in zip(segs, probs, drops_attn, ctx.masks):
             if len(seg) == 4:
                 _, S, Lq, off = seg
                 k_attn_bwd(qkv, p, dctx, S, Lq, H, drop=dr, out=dqkv, seq_off=off, ctx=ctxt)
                 continue
             S, Lq = seg
             k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr,
-                       out=dqkv[r0:r0 + S * Lq], ctx=ctxt[r0:r0 + S * Lq])
+                       out=dqkv[r0:r0 + S * Lq], ctx=ctxt[r0:r0 + S * Lq], mask_add=m)
             r0 += S * Lq
         _qkv_bwd(dqkv, x2, (wq, bq, wk, bk, wv, bv), D)
         dx = k_dgrad_t(dqkv, Wqkv_t, residual=dy1).view(xshape)    # + residual-path gradient, fused

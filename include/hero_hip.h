@@ -213,6 +213,10 @@ typedef struct HeroAttn {
   const int32_t* seq_off; /* optional [S+1] row offsets of a PACKED batch (L <= 64; bf16: 256): sequence s is */
                        /* rows [seq_off[s], seq_off[s+1]) of qkv/ctx/dctx/dqkv, at most L long;   */
                        /* probs keeps its [S, H, L, L] layout, dropout indices use L; mask NULL   */
+  float* stats;        /* optional [S, H, L, 2] fp32 (row maximum, 1 / row sum) of the softmax: fwd out, bwd in.  Where */
+                       /* hero_attention_stats_ok() says so, the backward takes stats INSTEAD of probs (probs NULL; it  */
+                       /* needs `mask` again) and recomputes the probabilities bit-identically from q, k: 24x less      */
+                       /* saved state at L = 24 (model/layers.py:129-160 keeps attention_probs for autograd)            */
 } HeroAttn;
 int hero_attention_fwd(const HeroAttn* a, hero_stream_t stream);
 int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream);
@@ -220,6 +224,9 @@ int hero_attention_max_len(int dtype, int backward);
 /* longest sequence of a PACKED (seq_off) batch the kernels take for this dtype: 256 on the bf16 matrix-core */
 /* kernels, 64 otherwise (fp32, or HERO_ATTN_MFMA=0) - callers fall back to the padded layout beyond it      */
 int hero_attention_max_packed_len(int dtype);
+/* 1 when forward + backward of this dtype / length run from `stats` without saved probabilities (bf16 matrix-core */
+/* kernels, L <= 64)                                                                                               */
+int hero_attention_stats_ok(int dtype, int L);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Row gathers / scatters                                                                       */

@@ -412,19 +412,38 @@ def test_attention_fwd_bwd(HF, Lb, dtype, S, L, H):
         m[1, 0] = 0                                   # subtitle without frames: first key masked
     madd = ((1 - m) * -10000.0).cuda()
     dctx = rnd(S * L, D, dtype=dtype, seed=2)
-    ctx, probs = HF.k_attn_fwd(qkv, madd, S, L, H)
+    ctx, saved = HF.k_attn_fwd(qkv, madd, S, L, H)
     q = qkv.float().requires_grad_(True)
     qq, kk, vv = [t.reshape(S, L, H, 64).permute(0, 2, 1, 3) for t in q.split(D, dim=1)]
     sc = qq @ kk.transpose(-1, -2) / 8.0 + madd[:, None, None, :]
     pr = torch.softmax(sc, -1)
     ref = (pr @ vv).permute(0, 2, 1, 3).reshape(S * L, D)
-    torch.testing.assert_close(probs, pr, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-3)
+    ptol = dict(rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5 if dtype == torch.float32 else 2e-3)
+    stats_mode = saved.dim() == 1
+    assert stats_mode == bool(Lb.lib().hero_attention_stats_ok(Lb.dt(qkv), L))
+    if stats_mode:
+        # bf16, L <= 64: the forward keeps (row max, 1 / row sum) instead of the probabilities ...
+        st = saved.view(S, H, L, 2)
+        mx = sc.max(-1).values
+        torch.testing.assert_close(st[..., 0], mx.detach(), rtol=2e-2, atol=5e-2)
+        torch.testing.assert_close(1.0 / st[..., 1], torch.exp(sc - mx[..., None]).sum(-1).detach(), rtol=2e-2, atol=2e-3)
+        HF.ATTN_SAVE_PROBS = True                     # ... the same kernels with the probabilities saved
+        try:
+            ctx_p, probs = HF.k_attn_fwd(qkv, madd, S, L, H)
+        finally:
+            HF.ATTN_SAVE_PROBS = False
+        assert probs.dim() == 4 and torch.equal(ctx_p, ctx)
+    else:
+        probs = saved
+    torch.testing.assert_close(probs, pr, **ptol)
     close(ctx, ref, dtype)
     if L > Lb.lib().hero_attention_max_len(Lb.dt(qkv), 1):
         return                                                    # forward-only length in this dtype
     ref.backward(dctx.float())
     dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, L, H, ctx=ctx)     # ctx: 64 < L <= 256 in bf16 runs on the matrix cores
     close(dqkv, q.grad, dtype, scale=2)
+    if stats_mode:                                                # rebuilt from q, k + statistics: the SAME bits
+        assert torch.equal(HF.k_attn_bwd(qkv, saved, dctx, S, L, H, ctx=ctx, mask_add=madd), dqkv)
     if dtype == torch.bfloat16 and L > 64:                        # ... and agrees with the fp32-VALU kernels (no ctx)
         close(dqkv, HF.k_attn_bwd(qkv, probs, dctx, S, L, H), dtype, scale=2)
 
@@ -446,10 +465,17 @@ def test_attention_packed_sequences(HF, dtype, lens, H):
     dqkv = HF.k_attn_bwd(qkv, probs, dctx, S, Lmax, H, seq_off=off, ctx=ctx)
     r0 = 0
     for s_, n in enumerate(lens):
-        c1, p1 = HF.k_attn_fwd(qkv[r0:r0 + n].contiguous(), None, 1, n, H)
+        HF.ATTN_SAVE_PROBS = probs.dim() == 4          # compare like with like (a long packed batch keeps its probabilities)
+        try:
+            c1, p1 = HF.k_attn_fwd(qkv[r0:r0 + n].contiguous(), None, 1, n, H)
+        finally:
+            HF.ATTN_SAVE_PROBS = False
         d1 = HF.k_attn_bwd(qkv[r0:r0 + n].contiguous(), p1, dctx[r0:r0 + n].contiguous(), 1, n, H, ctx=c1)
         close(ctx[r0:r0 + n], c1, dtype)
-        torch.testing.assert_close(probs[s_, :, :n, :n], p1[0], rtol=1e-5, atol=1e-6)
+        if probs.dim() == 4:
+            torch.testing.assert_close(probs[s_, :, :n, :n], p1[0], rtol=1e-5, atol=1e-6)
+        else:                                          # bf16, Lmax <= 64: softmax row statistics instead of probabilities
+            torch.testing.assert_close(probs.view(S, H, Lmax, 2)[s_, :, :n], p1.view(1, H, n, 2)[0], rtol=1e-5, atol=1e-6)
         close(dqkv[r0:r0 + n], d1, dtype, scale=2)
         r0 += n
     drop = HF.RNG.make(0.2, True, qkv.device)
@@ -489,7 +515,7 @@ def test_attention_dropout_adjoint(HF, Lb):
 
 
 @pytest.mark.parametrize("S,L,H", [(5, 24, 3), (3, 15, 2), (2, 60, 2), (2, 37, 1), (2, 100, 2), (2, 200, 3), (1, 256, 2)])
-def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
+def test_attention_mfma_dropout_matches_f32_kernels(HF, Lb, S, L, H):
     """The bf16 matrix-core attention kernels (L <= 64 and 64 < L <= 256) and the fp32 VALU kernels draw the SAME dropout
     mask for the same site (index = ((s*H+h)*L + q)*round_up(L,4) + k): forward and backward agree on
     bf16-representable inputs within the bf16 tolerance, and the adjoint identity holds."""
@@ -500,11 +526,20 @@ def test_attention_mfma_dropout_matches_f32_kernels(HF, S, L, H):
     m[0, L - 1] = 0
     madd = ((1 - m) * -10000.0).cuda()
     drop = HF.RNG.make(0.3, True, qkv16.device)
-    ctx16, probs16 = HF.k_attn_fwd(qkv16, madd, S, L, H, drop=drop)
+    HF.ATTN_SAVE_PROBS = True
+    try:
+        ctx16, probs16 = HF.k_attn_fwd(qkv16, madd, S, L, H, drop=drop)
+    finally:
+        HF.ATTN_SAVE_PROBS = False
     ctx32, probs32 = HF.k_attn_fwd(qkv16.float(), madd, S, L, H, drop=drop)
     torch.testing.assert_close(probs16, probs32, rtol=2e-2, atol=2e-3)
     close(ctx16, ctx32, torch.bfloat16)
     d16 = HF.k_attn_bwd(qkv16, probs32, dctx16, S, L, H, drop=drop, ctx=ctx16)
+    if Lb.lib().hero_attention_stats_ok(Lb.BF16, L):             # with dropout too: statistics alone give the same bits
+        ctx_s, stats = HF.k_attn_fwd(qkv16, madd, S, L, H, drop=drop)
+        assert stats.dim() == 1 and torch.equal(ctx_s, ctx16)
+        assert torch.equal(HF.k_attn_bwd(qkv16, stats, dctx16, S, L, H, drop=drop, ctx=ctx16, mask_add=madd),
+                           HF.k_attn_bwd(qkv16, probs16, dctx16, S, L, H, drop=drop, ctx=ctx16))
     if L <= 128:                                  # the fp32 backward is LDS-resident up to hero_attention_max_len(F32, 1)
         d32 = HF.k_attn_bwd(qkv16.float(), probs32, dctx16.float(), S, L, H, drop=drop)
         close(d16, d32, torch.bfloat16, scale=2)

@@ -47,7 +47,11 @@ __device__ __forceinline__ void store_headT(bf16_t* __restrict__ dst, int ld, in
   }
 }
 
-template <int NB, int WPB>
+// CLS (packed batches whose longest sequence needs NB = 2): 0 = every sequence, 1 = only sequences of <= 32 rows (run by
+// the NB = 1 kernel), 2 = only the longer ones (NB = 2 kernel).  A ragged TVR batch has 8-48 rows per subtitle: with one
+// NB = 2 launch every (sequence, head) pair paid for a 64 x 64 tile at one wave per SIMD - 70 / 110 us per layer forward /
+// backward against 16 / 23 us for the same rows at 24 per sequence (profiles/r03_kernel_stats_D2r.csv).
+template <int NB, int WPB, int CLS>
 __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
   const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
   if (L <= 0) return;
+  if ((CLS == 1 && L > 32) || (CLS == 2 && L <= 32)) return;      // wave-uniform: the other launch owns this sequence
   bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (32 * NB * RS);
   const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
   const bf16_t* kp = qp + D;
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, cx, lane);
 }
 
-template <int NB, int WPB, bool RC>       // RC: no saved probabilities - rebuilt from q, k and the saved row statistics
+template <int NB, int WPB, bool RC, int CLS>       // RC: no saved probabilities - rebuilt from q, k and the saved row statistics
 __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = 32 * NB;
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
   const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
   if (L <= 0) return;
+  if ((CLS == 1 && L > 32) || (CLS == 2 && L <= 32)) return;      // wave-uniform: the other launch owns this sequence
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + wave * WAVE_BYTES);
   bf16_t* Qs = Ks + R * RS;
   bf16_t* Os = Qs + R * RS;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   store_headT<NB>(dq + 2 * D, ld, L, gv, lane);
 }
 
-template <int NB, int WPB>
+template <int NB, int WPB, int CLS>
 int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
   constexpr int R = 32 * NB;
   const int pairs = a.S * a.H;
@@ -405,15 +411,15 @@ int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
     const size_t lds = (size_t)WPB * (3 * R * RS * 2 + 2 * R * (R + 8) * 2);
     static bool set = false;
     if (!set && lds > 65536) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, false, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, true, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       set = true;
     }
-    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false>), dim3(grid), dim3(64 * WPB), lds, s, a);
-    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
   } else {
     const size_t lds = (size_t)WPB * R * RS * 2;
-    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
   }
   return check_launch(bwd ? "hero_attention_bwd(mfma)" : "hero_attention_fwd(mfma)");
 }
@@ -422,8 +428,12 @@ int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
 
 // bf16, 1 <= L <= 64.  Called by attention.hip's dispatcher.
 int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s) {
-  if (a.L <= 32) return launch<1, 4>(a, bwd, s);
-  return launch<2, 1>(a, bwd, s);
+  if (a.L <= 32) return launch<1, 4, 0>(a, bwd, s);
+  if (a.seq_off) {                 // packed: two launches, each taking the sequences of its length class
+    const int rc = launch<1, 4, 1>(a, bwd, s);
+    return rc ? rc : launch<2, 1, 2>(a, bwd, s);
+  }
+  return launch<2, 1, 0>(a, bwd, s);
 }
 
 }  // namespace hero

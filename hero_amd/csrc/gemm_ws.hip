@@ -1339,11 +1339,17 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
     g.nsplit = 1;
     g.k_per_split = K;
     g.group = 8;
-    // Under one round of 192 x 192 tiles the launch lasts as long as ONE tile: 128 x 192 tiles (Geo<2, 3>) are
-    // shorter and use more of the CUs (M = 1920, N = 3072: 240 instead of 160 tiles; N = 2304: 180 instead of 120).
+    // Geometry by rounds: the persistent workgroups walk ceil(tiles / CUs) tiles each, and a 128 x 192 tile (Geo<2, 3>)
+    // costs ~0.75-0.8 of a 192 x 192 one (tools/lab/geo_ab.py: 11 vs 15 us per round at K = 768, 30 vs 40 at K = 3072).
+    // The smaller tile wins where it does not need proportionally more rounds:
+    //  * under one round (M = 1920, N = 3072: 240 instead of 160 tiles; N = 2304: 180 instead of 120);
+    //  * just over a round boundary of the 192 x 192 grid - the usual case of a ragged batch: M = 14450 rows, N = 768
+    //    = 304 tiles = 2 rounds at 59 % against 452 tiles of 128 x 192 = 2 rounds at 88 %: 32.4 -> 25.4 us (K = 768),
+    //    80.7 -> 67.0 (K = 3072).  The bench batch sits ON the boundary (12000 rows x 768 = 252 tiles) and keeps 192 x 192.
     typedef Geo<2, 3> G2;
     const int t23 = ((M + G2::BM - 1) / G2::BM) * g.tiles_n;
-    const bool small = force_cfg == 10 || (force_cfg == -1 && ntile * 5 < cus * 4 && t23 <= cus && t23 * 5 >= cus * 2);
+    const int r33 = (ntile + cus - 1) / cus, r23 = (t23 + cus - 1) / cus;
+    const bool small = force_cfg == 10 || (force_cfg == -1 && r23 * 4 < r33 * 5 && t23 * 5 >= cus * 2);
     if (small) {
       g.tiles_m = (M + G2::BM - 1) / G2::BM;
       g.nwork = t23;

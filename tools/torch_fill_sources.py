@@ -17,7 +17,7 @@ cfgp = "/tmp/hero_prof_cfg.json"
 json.dump(bench.HERO_BASE, open(cfgp, "w"))
 model = bench.build_model(dev, cfgp)
 tr = TrainStep(model, use_graph=False)
-batch = make_batch("D2", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev)
+batch = make_batch("D2", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev, ragged="ragged" in sys.argv)   # "ragged": the D2r batch
 for _ in range(4):
     tr.micro_step(batch)
 torch.cuda.synchronize()

@@ -17,5 +17,9 @@ python tools/profile_summary.py stats $OUT/${TAG}_stats_D4 6 $OUT/${TAG}_kernel_
 find $OUT/${TAG}_stats_D4 -name "*kernel_trace.csv" -delete
 (timeout 600 python bench.py --steps 20 --warmup 4) > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 (timeout 600 python bench.py --steps 20 --warmup 4 --feed 4 --no-cpu-baseline | tail -1) > $OUT/${TAG}_bench_feed.json 2>> $OUT/${TAG}_bench.err
+for w in D2r D3 D4; do
+  timeout 400 python bench.py --workload $w --no-cpu-baseline 2> $OUT/${TAG}_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
+done
+timeout 300 python bench.py --workload D2r --no-graph --no-cpu-baseline 2>> $OUT/${TAG}_D2r.err | tail -1 > $OUT/${TAG}_bench_D2r_eager.json
 tail -3 $OUT/${TAG}_run.log; cut -c1-200 $OUT/${TAG}_bench.json; cut -c1-200 $OUT/${TAG}_bench_feed.json
 for w in D2r D3 D4; do head -8 $OUT/${TAG}_kernel_stats_$w.csv | cut -c1-140; done

@@ -301,9 +301,10 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
       const int row = r0 + it * RPI;
       const int gm = ic.m0 + tile_row(p, row);
       ok[it] = col_ok && row < RPP && gm < g.M;
-      off[it] = (unsigned)min(gm, g.M - 1) * (unsigned)g.ldc + (unsigned)gnc;
-      if (EK & EK_RES) pre[it] = *reinterpret_cast<const uint4*>(R + off[it]);
-      if (EK & EK_GELU_BWD) pre[it] = *reinterpret_cast<const uint4*>(X + off[it]);
+      // tile-relative (like the stores): the matrix itself may hold more than 2^32 elements (config 5: 1.5 M rows x 3072)
+      off[it] = (unsigned)(min(gm, g.M - 1) - ic.m0) * (unsigned)g.ldc + (unsigned)(gnc - ic.n0);
+      if (EK & EK_RES) pre[it] = *reinterpret_cast<const uint4*>(R + torg + off[it]);
+      if (EK & EK_GELU_BWD) pre[it] = *reinterpret_cast<const uint4*>(X + torg + off[it]);
     }
     WS_T(trace_item, 2 + 4 * p, wave, lane);
     if constexpr (COMPUTE) {
@@ -1335,7 +1336,9 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
   const int cus = num_cus();
   if (kk) {
     if (K % 64 != 0 || epi.out_f32 || epi.split_k > 1) return -1;
-    if ((size_t)M * lda * 2 >= 0x7fffffffull || (size_t)N * ldb * 2 >= 0x7fffffffull || (size_t)M * ldc >= 0x7fffffffull) return -1;
+    // every per-lane offset of this family is relative to its tile (operand panels, residual / saved pre-activation reads,
+    // stores); only the weight matrix B is addressed from its base
+    if ((size_t)N * ldb * 2 >= 0x7fffffffull || (size_t)192 * lda * 2 >= 0x7fffffffull || (size_t)192 * ldc * 2 >= 0x7fffffffull) return -1;
     g.nsplit = 1;
     g.k_per_split = K;
     g.group = 8;

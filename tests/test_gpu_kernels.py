@@ -122,6 +122,38 @@ def test_gemm_wave_specialised_128x192_tiles(HF, Lb, M, N, K):
     _ws_against_4wave(HF, Lb, M, N, K, 10)
 
 
+def test_gemm_wave_specialised_large_row_counts(HF, Lb):
+    """config 5 sizes (long videos filling the HBM): 1.45 M rows - the activations exceed 2^32 elements / 2^31 bytes.  The
+    wave-specialised K,K kernels address everything relative to the tile (panels, residual and saved pre-activation
+    reads, stores) and must agree with the 4-wave kernels on the last rows too."""
+    dtype = torch.bfloat16
+    M = 1_450_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def big(rows, cols, scale=1.0):
+        return (torch.randn(rows, cols, device="cuda", generator=g, dtype=torch.float32) * scale).to(dtype) if rows * cols < 2 ** 28 else \
+            torch.cat([(torch.randn(rows // 10, cols, device="cuda", generator=g, dtype=torch.float32) * scale).to(dtype) for _ in range(10)], 0)
+
+    for N, K, kind in ((768, 3072, "res"), (3072, 768, "gelu_bwd")):
+        x, w = big(M, K), big(N, K, 0.05)
+        side = big(M, N)                                             # residual / saved pre-activation
+        assert x.numel() > 2 ** 31 or side.numel() > 2 ** 32
+        outs = []
+        for cfg in (-1, 8):                                          # heuristic (wave-specialised) / never
+            Lb.lib().hero_gemm_force_config(cfg)
+            try:
+                if kind == "res":
+                    outs.append(HF.k_linear(x, w, residual=side))
+                else:
+                    outs.append(HF.k_dgrad_t(x, w, act=Lb.ACT_GELU_BWD, aux=side))
+            finally:
+                Lb.lib().hero_gemm_force_config(-1)
+        for sl in (slice(0, 4096), slice(M // 2, M // 2 + 4096), slice(M - 4096, M)):
+            close(outs[0][sl], outs[1][sl], dtype, scale=math.sqrt(K) * 0.05 + 1)
+        del x, w, side, outs
+        torch.cuda.empty_cache()
+
+
 def _ws_against_4wave(HF, Lb, M, N, K, ws_cfg):
     dtype = torch.bfloat16
     x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)

@@ -280,6 +280,30 @@ def test_memo_tracks_identity_and_version():
     assert len(calls) == 4
 
 
+def test_stack_and_split_rows_are_cat_and_slices_for_autograd():
+    """functional.StackRowsFn / SplitRowsFn (the sub + query stack of BertEncoder.forward_multi) are torch.cat and row
+    slices as far as autograd is concerned - including a block that receives no gradient."""
+    from hero_amd import functional as HF
+    torch.manual_seed(0)
+    a = torch.randn(5, 8, requires_grad=True)
+    b = torch.randn(3, 8, requires_grad=True)
+    w0, w1 = torch.randn(5, 8), torch.randn(3, 8)
+    x = HF.StackRowsFn.apply(a, b)
+    assert torch.equal(x, torch.cat([a, b], 0))
+    y0, y1 = HF.SplitRowsFn.apply(x * 2.0, 5, 3)
+    ((y0 * w0).sum() + (y1.view(3, 8) * w1).sum()).backward()
+    ra, rb = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    rx = torch.cat([ra, rb], 0) * 2.0
+    ((rx[:5] * w0).sum() + (rx[5:] * w1).sum()).backward()
+    torch.testing.assert_close(a.grad, ra.grad)
+    torch.testing.assert_close(b.grad, rb.grad)
+    a.grad = b.grad = None
+    y0, y1 = HF.SplitRowsFn.apply(HF.StackRowsFn.apply(a, b) * 3.0, 5, 3)
+    (y1 * w1).sum().backward()                       # the first block gets no gradient: zeros, not garbage
+    assert torch.equal(a.grad, torch.zeros_like(a))
+    torch.testing.assert_close(b.grad, 3.0 * w1)
+
+
 def test_no_memset_nodes_in_the_kernel_library():
     """hipMemsetAsync inside a captured hipGraph is not ordered like the kernel nodes around it on this
     stack (round 1: the ranking-loss buffer was zeroed by a memset node that raced with the kernel that

@@ -120,7 +120,8 @@ int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int dtype, con
                      hero_stream_t stream);
 int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
                                       * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
-                                      * bits 8+: M-tiles per L2 locality group; -1 heuristic */
+                                      * bits 8+: M-tiles per L2 locality group; 8 / 9 / 10: the wave-specialised
+                                      * kernels never / always with 192x192 / always with 128x192 tiles; -1 heuristic */
 int hero_prof_enable(int on);
 int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches);
 

@@ -87,7 +87,7 @@ int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int ld
 /* Per-launch timing of hero_gemm with HIP events recorded on the launch stream (bench.py's
  * roofline leg; off by default, never enable inside graph capture).
  * slot = (dtype == HERO_BF16 ? 4 : 0) + a_layout * 2 + b_layout for the 4-wave kernels, 8 / 9 for the
- * wave-specialised K,K / O,O kernels (gemm_ws.hip). hero_prof_read synchronises. */
+ * wave-specialised 192x192 K,K / O,O kernels, 10 for the 128x192 K,K tiles (gemm_ws.hip). hero_prof_read synchronises. */
 /* Grouped weight gradient: dw_p[M_p, N_p] (fp32) += dy_p[K, :M_p]^T x_p[K, :N_p] for 1..4 problems that reduce over
  * the same K rows - the four nn.Linear weights of a BertLayer (model/layers.py:125-127, 176, 237, 251) - in ONE
  * launch (stream-K over the (tile, k) space of the whole group, fp32 atomics into dw).  Small / unaligned / fp32

@@ -280,6 +280,63 @@ def test_memo_tracks_identity_and_version():
     assert len(calls) == 4
 
 
+@pytest.mark.parametrize("rows,layers,extra", [(12000, 6, ()), (1920, 3, ((768, 4352),)), (12040, 1, ()), (786432, 2, ())])
+def test_wgrad_batch_plan_covers_every_tile_once(built_lib, rows, layers, extra):
+    """hero_wgrad_batch_plan is host code (no GPU): every 192 x 192 tile of every problem appears exactly once per
+    k-step; full rounds hold whole tiles; the k-slices of a tail tile are contiguous, ordered, share one flag and one
+    XCD (workgroup ids w with equal w // (nwg / 8)), and no two tail tiles share a flag."""
+    from hero_amd import _lib as L
+    lib = L.lib()
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * layers + list(extra)
+    n = len(shapes)
+    probs = (L.WgradProblem * n)()
+    for i, (m, k) in enumerate(shapes):
+        probs[i] = L.WgradProblem(0, 0, 0, m, k, m, k, k, 4)
+    buf = np.zeros(8 + 8 * 512 * 16, dtype=np.int32)
+    words = lib.hero_wgrad_batch_plan(probs, n, rows, buf.ctypes.data, buf.size)
+    assert words > 8, lib.hero_last_error()
+    magic, nwg, rounds, items, n_, K, tiles, S = buf[:8]
+    assert (n_, K, items, words) == (n, rows, rounds * nwg, 8 + rounds * nwg * 8) and nwg % 8 == 0
+    ksteps = -(-rows // 64)
+    plan = buf[8:words].reshape(rounds, nwg, 8)
+    expect = {(i, a * 192, b * 192) for i, (m, k) in enumerate(shapes) for a in range(-(-m // 192)) for b in range(-(-k // 192))}
+    assert tiles == len(expect)
+    cover, flags = {}, {}
+    for r in range(rounds):
+        for w in range(nwg):
+            prob, m0, n0, k0, nk, order, nslices, flag = plan[r, w]
+            if nk == 0:
+                continue                                      # idle slot of the tail round
+            key = (int(prob), int(m0), int(n0))
+            assert key in expect
+            cover.setdefault(key, []).append((int(order), int(k0), int(nk), int(nslices), r, w, int(flag)))
+            if r < rounds - 1 or tiles % nwg == 0:
+                assert (k0, nk, order, nslices) == (0, ksteps, 0, 1)          # a full round: whole tiles, no merge
+    assert set(cover) == expect
+    for key, parts in cover.items():
+        parts.sort()
+        assert [p[0] for p in parts] == list(range(len(parts))) and all(p[3] == len(parts) for p in parts)
+        assert parts[0][1] == 0 and sum(p[2] for p in parts) == ksteps
+        assert all(a[1] + a[2] == b[1] for a, b in zip(parts, parts[1:]))     # contiguous, in slice order
+        if len(parts) > 1:
+            assert len({p[4] for p in parts}) == 1                            # one round
+            assert len({p[5] // (nwg // 8) for p in parts}) == 1              # one XCD: the merge stays in its L2
+            assert len({p[6] for p in parts}) == 1
+            assert flags.setdefault(parts[0][6], key) == key                  # a flag per tail tile
+            assert min(p[2] for p in parts) >= 4
+
+
+def test_attention_capability_queries(built_lib):
+    """Host-side capability queries the Python layer branches on (no GPU needed): which lengths run packed, and where the
+    backward works from the softmax row statistics instead of saved probabilities."""
+    from hero_amd import _lib as L
+    lib = L.lib()
+    assert lib.hero_attention_max_packed_len(L.BF16) == 256 and lib.hero_attention_max_packed_len(L.F32) == 64
+    assert [lib.hero_attention_stats_ok(L.BF16, n) for n in (1, 24, 64, 65, 256)] == [1, 1, 1, 0, 0]
+    assert lib.hero_attention_stats_ok(L.F32, 24) == 0
+    assert lib.hero_attention_max_len(L.BF16, 1) == 256 and lib.hero_attention_max_len(L.F32, 0) >= 256
+
+
 def test_stack_and_split_rows_are_cat_and_slices_for_autograd():
     """functional.StackRowsFn / SplitRowsFn (the sub + query stack of BertEncoder.forward_multi) are torch.cat and row
     slices as far as autograd is concerned - including a block that receives no gradient."""

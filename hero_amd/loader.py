@@ -1,6 +1,7 @@
 """Host -> device hand-over of batches, one step ahead (loader half).
 
-`PrefetchLoader` is the reference's class of the same name (data/loader.py:89-144): it wraps any iterable of host
+`MetaLoader` is the reference's multi-task scheduler (data/loader.py:19-59), `PrefetchLoader` the reference's class of the
+same name (data/loader.py:89-144): it wraps any iterable of host
 batches (a DataLoader with `collate_fn=hero_amd.collate.vcmr_collate` and `pin_memory=True`), moves batch k + 1 to the
 device on a side stream while batch k is being consumed, and yields device batches - same protocol (`wait_stream`
 before the hand-over, `record_stream` on every tensor), so a reference training loop takes it unchanged.
@@ -48,6 +49,55 @@ def _record_stream(batch, stream):
     elif isinstance(batch, (list, tuple)):
         for v in batch:
             _record_stream(v, stream)
+
+
+class MetaLoader:
+    """Scheduler of a multi-task run (the reference's class of this name, data/loader.py:19-59; pretrain.py's loop
+    iterates it): yields `(task, batch)` forever.
+
+    loaders        {task: DataLoader} or {task: (any iterable of batches, ratio)} - a task's chance is proportional to its
+                   integer ratio (1 for a bare DataLoader); anything else raises ValueError, as in the reference
+    accum_steps    a new task is drawn (Python's `random`) only every accum_steps micro-steps: an accumulation window
+                   stays on one task
+    distributed    rank 0's draw is broadcast, so every rank trains the same task (the reference's Horovod
+                   `any_broadcast`; here `hero_amd.utils.distributed.any_broadcast` over the process group)
+    A loader that runs out is restarted.  Attributes name2loader / name2iter / sampling_pools / step are the reference's."""
+
+    def __init__(self, loaders, accum_steps=1, distributed=False):
+        assert isinstance(loaders, dict)
+        self.name2loader, self.sampling_pools = {}, []
+        for task, entry in loaders.items():
+            if isinstance(entry, tuple):
+                loader, ratio = entry
+            elif isinstance(entry, torch.utils.data.DataLoader):
+                loader, ratio = entry, 1
+            else:
+                raise ValueError()
+            self.name2loader[task] = loader
+            self.sampling_pools += [task] * ratio
+        self.name2iter = {task: iter(loader) for task, loader in self.name2loader.items()}
+        self.accum_steps, self.distributed, self.step = accum_steps, distributed, 0
+
+    def _draw(self):
+        import random
+        from .utils.distributed import any_broadcast
+        task = random.choice(self.sampling_pools)
+        return any_broadcast(task, 0) if self.distributed else task
+
+    def _batch_of(self, task):
+        try:
+            return next(self.name2iter[task])
+        except StopIteration:
+            self.name2iter[task] = iter(self.name2loader[task])
+            return next(self.name2iter[task])
+
+    def __iter__(self):
+        task = self.sampling_pools[0]
+        while True:
+            if self.step % self.accum_steps == 0:
+                task = self._draw()
+            self.step += 1
+            yield task, self._batch_of(task)
 
 
 class PrefetchLoader:

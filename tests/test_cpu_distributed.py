@@ -342,3 +342,49 @@ def _negatives_uniform(rank, world):
 
 def test_gather_negatives_uniform_shapes_skips_the_size_exchange():
     assert all(spawn(_negatives_uniform))
+
+
+def _meta_loader(rank, world):
+    """MetaLoader (data/loader.py:19-59): with distributed=True every rank follows rank 0's task draws although the
+    ranks' own random streams differ; a window of accum_steps micro-steps stays on one task; loaders restart."""
+    import random
+    from hero_amd.loader import MetaLoader
+    random.seed(100 + rank)                                     # different streams: only the broadcast can align them
+    loaders = {"mlm": ([("mlm", rank, i) for i in range(3)], 2), "vsm": ([("vsm", rank, i) for i in range(5)], 1)}
+    ml = MetaLoader(loaders, accum_steps=2, distributed=True)
+    seq = []
+    for k, (task, batch) in enumerate(ml):
+        assert batch[0] == task and batch[1] == rank
+        seq.append((task, batch[2]))
+        if k == 39:
+            break
+    return seq
+
+
+def test_meta_loader_ranks_follow_rank0():
+    a, b = spawn(_meta_loader)
+    assert a == b                                               # same tasks AND same positions inside each task's loader
+    tasks = [t for t, _ in a]
+    assert all(tasks[i] == tasks[i + 1] for i in range(0, 40, 2))          # accumulation windows are single-task
+    assert {"mlm", "vsm"} == set(tasks)
+    mlm_pos = [i for t, i in a if t == "mlm"]
+    assert mlm_pos[:4] == [0, 1, 2, 0]                          # restarted after three batches
+
+
+def test_meta_loader_single_process_contract():
+    import random
+    import pytest
+    from torch.utils.data import DataLoader
+    from hero_amd.loader import MetaLoader
+    with pytest.raises(ValueError):
+        MetaLoader({"a": [1, 2, 3]})                             # neither a DataLoader nor (loader, ratio)
+    dl = DataLoader(list(range(4)), batch_size=2)
+    ml = MetaLoader({"a": dl, "b": (["x"], 3)}, accum_steps=1)
+    assert ml.sampling_pools == ["a", "b", "b", "b"] and ml.step == 0
+    random.seed(0)
+    got = []
+    for task, batch in ml:
+        got.append(task)
+        if len(got) == 400:
+            break
+    assert ml.step == 400 and 0.65 < got.count("b") / 400 < 0.85           # ratio 3 : 1

@@ -95,3 +95,45 @@ def test_reader_matches_the_reference_reader_on_reference_written_records():
         assert torch.equal(dflt[n], torch.from_numpy(g["out_default." + n]))
     assert g["out_default.tvr_d"].shape[0] == 0 and g["out_default.tvr_a"].shape[0] == 129      # the -1 quirk is the reference's
     assert featdb.VideoFeatReader(store, None, compress=True, max_clip_len=100).name2nframe == json.loads(g["nframe"].tobytes().decode())
+
+
+@pytest.mark.parametrize("compress", [True, False])
+def test_reader_feeds_the_collate_to_the_reference_batch(compress):
+    """End of the data path: features stored as database records (fp16 on disk, as the released TVR features are) ->
+    VideoFeatReader (clip at max_clip_len) -> video_item / vcmr_collate = the batch the reference's own dataset + collate
+    produced for the `narrow` case of tests/golden/case_collate.npz (its features are fp16-exact by construction of this
+    test: they are rounded once before both paths would see them - here only the integer tensors and the clip are compared
+    bit for bit, the features within fp16 rounding)."""
+    import os
+    from tests.util import GOLDEN
+    from hero_amd import collate as C
+    Z = np.load(os.path.join(GOLDEN, "case_collate.npz"))
+    case = "narrow"
+    desc = json.loads(str(Z[case + ".desc"]))
+    want = {k[len(case) + 5:]: Z[k] for k in Z.files if k.startswith(case + ".out.")}
+    store, nframe = {}, {}
+    for v in desc["videos"]:
+        f = Z["%s.feat.%s" % (case, v["vid"])]
+        store[v["vid"].encode()] = featdb.encode_record(f.astype(np.float16), compress)
+        nframe[v["vid"]] = len(f)
+    rd = featdb.VideoFeatReader(store, nframe, compress=compress, max_clip_len=desc["max_clip_len"])
+    s2f_all = json.loads(str(want["sub_idx2frame_idx"]))
+    items = []
+    by_vid = {v["vid"]: (i, v) for i, v in enumerate(desc["videos"])}
+    for qid in desc["query_order"]:
+        vi, v = by_vid["v" + qid[1:3]]
+        feat = rd[v["vid"]]
+        assert feat.shape[0] == min(nframe[v["vid"]], desc["max_clip_len"])
+        video = C.video_item(feat, [(sid, list(fr)) for sid, fr in s2f_all[vi]], v["sub_tokens"], sep=2)
+        q = v["queries"][int(qid.split("_")[1])]
+        items.append(C.vcmr_item(video, v["vid"], [(q["tokens"], q["ts"])], cls_=0, frame_interval=desc["frame_interval"]))
+    got = C.vcmr_collate(items)
+    for k, w in want.items():
+        if w.dtype.kind == "U":
+            continue
+        g = got[k]
+        assert tuple(g.shape) == w.shape, k
+        if w.dtype.kind == "f":
+            torch.testing.assert_close(g, torch.from_numpy(w), rtol=1e-3, atol=1e-3)       # fp16 storage
+        else:
+            assert torch.equal(g, torch.from_numpy(w)), k

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libhero_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "gemm_ws.hip", "layernorm.hip", "attention.hip", "attention_mfma.hip", "attention_mfma_long.hip", "rows.hip", "head.hip", "loss.hip", "collate.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "gemm_ws.hip", "gemm_wsd.hip", "layernorm.hip", "attention.hip", "attention_mfma.hip", "attention_mfma_long.hip", "rows.hip", "head.hip", "loss.hip", "collate.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 
@@ -32,7 +32,7 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(CSRC, "attn_mfma.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(CSRC, "gemm_ws_common.h"), os.path.join(CSRC, "attn_mfma.h"),
                os.path.join(os.path.dirname(HERE), "include", "hero_hip.h")]
     jobs = []
     objs = []

@@ -939,9 +939,12 @@ static int launch_kk(const WsArgs& g, hipStream_t s) {
 // gemm_wsd.hip: the same problems on the kernel whose epilogue is drained by the loader waves during the next main loop
 template <int TM, int TN> int launch_kk_deferred(const WsArgs& g, hipStream_t s);
 
-// Deferred epilogue by default (HERO_WS_DEFER=0 restores the in-line epilogue of round 2/3 for A/B runs)
+// The deferred epilogue is OFF by default: measured on MI355X (tools/lab/wsd_ab.py, profiles/r04_wsd_ab.txt) it is 1.0-1.3x
+// SLOWER than the in-line one on every epilogue that has arithmetic (bit-equal results).  The loader waves have no slack:
+// they sit in the issue of the 12 DMA pieces of a step for ~1200 of its ~1660 cycles (the L2 -> LDS fill is as critical
+// as the MFMAs), so every VALU instruction and every store they carry delays the ring.  HERO_WS_DEFER=1 / force 11, 12.
 static bool defer_default() {
-  static const bool on = [] { const char* v = getenv("HERO_WS_DEFER"); return !(v && v[0] == '0'); }();
+  static const bool on = [] { const char* v = getenv("HERO_WS_DEFER"); return v && v[0] == '1'; }();
   return on;
 }
 

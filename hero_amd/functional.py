@@ -371,6 +371,7 @@ WGRAD_BATCH = [int(os.environ.get("HERO_WGRAD_BATCH", "32"))]   # 4: the per-lay
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5
 _WQ_BYTES = [0]                                                  # sizes its batch to 90 % of HBM: there it flushes at once)
 _WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) or None when the group is too small
+_WPLANS_PINNED = set()   # keys whose plan tensor a captured graph references by address
 
 
 def _wgrad_limit():
@@ -386,9 +387,15 @@ def _wgrad_plan(probs, n, rows, device):
         if words < 0:
             L.check(words)
         hit = (torch.from_numpy(buf[:words].copy()).to(device), words) if words > 0 else None
-        if len(_WPLANS) > 64:
-            _WPLANS.clear()
+        # Plans are never dropped while a captured hipGraph may hold their device address (as optim.adamw pins its
+        # tables): entries made or used under stream capture are pinned; the rest of the cache (ragged eager batches make
+        # a key per distinct row count) is bounded.
+        if len(_WPLANS) > 256:
+            for k in [k for k in _WPLANS if k not in _WPLANS_PINNED][:128]:
+                del _WPLANS[k]
         _WPLANS[key] = hit
+    if hit is not None and torch.cuda.is_current_stream_capturing():
+        _WPLANS_PINNED.add(key)
     return hit
 
 
@@ -455,8 +462,20 @@ def wgrad_flush():
     _WQ_BYTES[0] = 0
     while _WQ:
         rows, dtype = _WQ[0][0].shape[0], _WQ[0][0].dtype
+        # One launch never holds the same destination twice: full-round tiles of hero_wgrad_batch do a plain (non-atomic)
+        # read-add-write of dW and of the riding bias sums, so a parameter used twice in one backward pass with equal row
+        # counts (a shared / tied nn.Linear, fuse_query_pass=False with coinciding row counts) goes into consecutive
+        # launches, which the stream orders - as colsum_flush does.
+        dst_key = lambda e: (e[2].data_ptr(), e[6].data_ptr() if e[6] is not None else None)     # noqa: E731
+        seen_w, seen_b = {_WQ[0][2].data_ptr()}, {dst_key(_WQ[0])[1]} - {None}
         n = 1
         while n < len(_WQ) and n < 32 and _WQ[n][0].shape[0] == rows and _WQ[n][0].dtype == dtype:
+            kw, kb = dst_key(_WQ[n])
+            if kw in seen_w or (kb is not None and kb in seen_b):
+                break
+            seen_w.add(kw)
+            if kb is not None:
+                seen_b.add(kb)
             n += 1
         group, rest = _WQ[:n], _WQ[n:]
         del _WQ[:]

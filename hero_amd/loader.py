@@ -29,13 +29,16 @@ DERIVED = ("f_v_feats", "f_attn_masks", "f_gather_index", "c_attn_masks")
 
 
 def move_to_device(batch, device, non_blocking=True):
-    """data/loader.py:49-66 (move_to_cuda): tensors, lists / tuples / dicts of tensors; anything else passes through."""
+    """data/loader.py:49-66 (move_to_cuda): tensors are moved, lists / tuples / dicts are walked RECURSIVELY (the reference
+    wraps `PrefetchLoader(MetaLoader(...))`, whose items are `(task, batch_dict)` tuples); anything else passes through."""
     if torch.is_tensor(batch):
         return batch.to(device, non_blocking=non_blocking)
     if isinstance(batch, dict):
         return {k: move_to_device(v, device, non_blocking) for k, v in batch.items()}
-    if isinstance(batch, (list, tuple)) and batch and all(torch.is_tensor(t) for t in batch):
-        return type(batch)(t.to(device, non_blocking=non_blocking) for t in batch)
+    if isinstance(batch, tuple) and hasattr(batch, "_fields"):          # namedtuple
+        return type(batch)(*(move_to_device(v, device, non_blocking) for v in batch))
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(move_to_device(v, device, non_blocking) for v in batch)
     return batch
 
 

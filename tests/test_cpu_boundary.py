@@ -373,3 +373,20 @@ def test_no_memset_nodes_in_the_kernel_library():
         if path.endswith((".hip", ".cpp", ".h")):
             code = "\\n".join(line.split("//")[0] for line in open(path).read().splitlines())
             assert "hipMemset" not in code, path
+
+
+def test_move_to_device_recurses_like_the_reference():
+    """data/loader.py:49-66 (move_to_cuda): lists, tuples and dicts are walked recursively - `PrefetchLoader(MetaLoader(...))`
+    hands `(task, batch_dict)` tuples to it (pretrain.py:177-180).  Checked with the `meta` device (no GPU needed)."""
+    import collections
+    import torch
+    from hero_amd.loader import move_to_device
+    t = lambda: torch.zeros(2, 3)                                              # noqa: E731
+    NT = collections.namedtuple("NT", ["a", "b"])
+    item = ("tvr", {"x": t(), "nested": [t(), (t(), 7, "s")], "lens": [3, 4], "nt": NT(t(), None)})
+    out = move_to_device(item, torch.device("meta"))
+    assert out[0] == "tvr" and isinstance(out, tuple)
+    b = out[1]
+    assert b["x"].device.type == "meta" and b["nested"][0].device.type == "meta" and b["nested"][1][0].device.type == "meta"
+    assert b["nested"][1][1:] == (7, "s") and b["lens"] == [3, 4] and isinstance(b["nested"][1], tuple)
+    assert isinstance(b["nt"], NT) and b["nt"].a.device.type == "meta" and b["nt"].b is None

@@ -388,6 +388,36 @@ def test_deferred_weight_gradients_are_flushed_with_the_backward_pass(HF, Lb):
         torch.testing.assert_close(w.grad, r.grad, rtol=5e-2, atol=5e-2 * float(r.grad.abs().max()))
 
 
+def test_deferred_weight_gradients_same_destination_twice(HF, Lb):
+    """a parameter used twice in one backward pass with equal row counts (tied / shared nn.Linear) queues two
+    problems with the SAME dW and dbias.  Inside one hero_wgrad_batch launch both would sit in the same round on different
+    workgroups and the plain read-add-write of the full-round tiles would lose one of them; wgrad_flush cuts the batch."""
+    rows, n_out, n_in = 4096, 1536, 3072                 # 128 tiles per use: both uses would share one round of 256
+    dys = [rnd(rows, n_out, dtype=torch.bfloat16, seed=1 + k) for k in range(2)]
+    xs = [rnd(rows, n_in, dtype=torch.bfloat16, seed=5 + k) for k in range(2)]
+    dW = torch.ones(n_out, n_in, device="cuda")
+    db = torch.ones(n_out, device="cuda")
+
+    class Use(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t, k):
+            ctx.k = k
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            HF.k_wgrad(dys[ctx.k], xs[ctx.k], out=dW, beta=1.0, dbias=db, dbias_done=lambda: None)
+            return g, None
+
+    t = torch.zeros(4, device="cuda", requires_grad=True)
+    Use.apply(Use.apply(t, 0), 1).sum().backward()
+    torch.cuda.synchronize()
+    ref = 1.0 + sum(d.float().t() @ x.float() for d, x in zip(dys, xs))
+    refb = 1.0 + sum(d.float().sum(0) for d in dys)
+    torch.testing.assert_close(dW, ref, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    torch.testing.assert_close(db, refb, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(700, 776, 768), (12000, 3072, 768), (130, 64, 64)])
 def test_gemm_output_column_sums(HF, Lb, dtype, M, N, K):

@@ -113,3 +113,23 @@ def test_feeder_rejects_other_shapes():
     f = StaticBatchFeeder(pin_batch(a), "cuda", capture_commit=False)
     with pytest.raises(ValueError):
         f.prefetch(pin_batch(b))
+
+
+@pytest.mark.gpu
+def test_prefetch_loader_over_meta_loader_moves_the_whole_batch():
+    """The reference's composition `PrefetchLoader(MetaLoader(...))` (pretrain.py:177-180, train_vcmr.py:83-86): items are
+    `(task, batch_dict)` tuples, nested lists / tuples included - every tensor must arrive on the device."""
+    import torch
+    from hero_amd.loader import MetaLoader, PrefetchLoader
+    batches = [{"x": torch.full((4,), float(i)), "pair": (torch.ones(2) * i, [torch.zeros(1), "keep"]), "n": i} for i in range(3)]
+    ml = MetaLoader({"tvr": (batches, 1)}, accum_steps=1)
+    seen = 0
+    for task, batch in PrefetchLoader(ml, device="cuda"):
+        assert task == "tvr"
+        assert batch["x"].is_cuda and batch["pair"][0].is_cuda and batch["pair"][1][0].is_cuda
+        assert batch["pair"][1][1] == "keep" and batch["n"] == seen % 3
+        assert float(batch["x"][0]) == float(seen % 3)
+        seen += 1
+        if seen == 5:
+            break
+    assert seen == 5

@@ -1137,7 +1137,79 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
   const int T = (int)tiles.size();
   const int full = T / nwg, rem = T % nwg;
   if (full == 0 && T < nwg / 4) return 0;          // a handful of tiles: the stream-K group kernel cuts finer
-  const int rounds = full + (rem ? 1 : 0);
+  // Tail (tiles % nwg != 0): the remaining tiles are dealt to the XCDs (per_xcd each) and every XCD balances its p tiles
+  // over its c = nwg / 8 workgroups.  Each workgroup gets a quota of q = ceil(p ksteps / c) k-steps:
+  //   * every tile is cut into S = floor(c / p) "big" slices of q steps on S x p workgroups (round 0 of the tail);
+  //   * what is left of each tile (r = ksteps - S q steps) is packed, tile after tile, into the L = c - S p workgroups
+  //     that are still free, up to q steps each - one piece per extra tail round, a piece may be cut at a workgroup boundary.
+  // Round 3 had the equal slices only (S = floor(c / p), L workgroups idle): 192 tiles - ONE BertLayer, which is all the
+  // byte cap of the queue lets config 5 batch - ran on 192 of 256 workgroups.  Now every workgroup carries ~q steps.
+  // Slice order (the fp32 atomics of a tile are applied in this order, which keeps dW bit-reproducible) follows the
+  // time a piece completes when nobody waits: the head piece of a cut remainder first, then its other piece, then the
+  // big slices - so a waiting piece only ever waits for pieces that finish earlier, and the k-ranges are laid out in
+  // the same order (remainder pieces at the start of the reduction, big slices behind them).
+  struct Piece { int slot, round, tile, k0, nk, order, nslices; };
+  std::vector<Piece> pieces;
+  int tail_rounds = rem ? 1 : 0, S = 1;
+  const int per_xcd_cap = nwg / 8, per_xcd = rem ? (rem + 7) / 8 : 0;
+  if (rem) {
+    HERO_REQUIRE(per_xcd <= 512 / 8, "hero_wgrad_batch_plan: flag capacity");
+    for (int xcd = 0; xcd * per_xcd < rem; ++xcd) {
+      const int t0 = xcd * per_xcd, p = (rem - t0 < per_xcd) ? rem - t0 : per_xcd, c = per_xcd_cap;
+      int q = (int)(((long long)p * ksteps + c - 1) / c);
+      if (q < 4) q = 4;
+      int Sx = c / p;
+      if (Sx > ksteps / q) Sx = ksteps / q;
+      if (Sx > 8) Sx = 8;
+      if (Sx < 1) Sx = 1;
+      int L = c - Sx * p;
+      int r = ksteps - Sx * q;
+      if (r < 0) r = 0;
+      // no free workgroup / nothing worth a piece / the slice cap already reached (every slice adds a tile of atomics):
+      // equal big slices only
+      if (L == 0 || r < 2 || (Sx == 8 && c / p > 8)) r = 0;
+      if (xcd == 0) S = Sx;
+      // remainder pieces: walk the free workgroups
+      std::vector<std::vector<Piece>> of_tile(p);
+      int slot = Sx * p, fillq = 0, rnd = 0;
+      for (int t = 0; t < p && r > 0; ++t) {
+        int left = r;
+        std::vector<Piece> mine;
+        while (left > 0) {
+          int room = q - fillq;
+          if (slot >= c - 1) room = left;             // the last free workgroup takes what is left (rounding)
+          else if (room < 2 || (room < left && left - room < 2)) {
+            if (room < 2) { ++slot; fillq = 0; rnd = 0; continue; }
+            room = left;                               // do not leave a 1-step crumb for the next workgroup
+          }
+          const int take = left < room ? left : room;
+          mine.push_back({slot < c ? slot : c - 1, rnd, t, 0, take, 0, 0});
+          left -= take; fillq += take; ++rnd;
+          if (fillq >= q && slot < c - 1) { ++slot; fillq = 0; rnd = 0; }
+        }
+        // completion order: a later-emitted piece sits at the head of the next workgroup and finishes first
+        int k0 = 0, ord = 0;
+        for (int i = (int)mine.size() - 1; i >= 0; --i) { mine[i].k0 = k0; mine[i].order = ord++; k0 += mine[i].nk; }
+        of_tile[t] = mine;
+      }
+      for (int t = 0; t < p; ++t) {
+        const int nrem = (int)of_tile[t].size();
+        const int big0 = r;                            // big slices cover [r, ksteps)
+        for (int sl = 0; sl < Sx; ++sl) {
+          const int k0 = big0 + (int)((long long)(ksteps - big0) * sl / Sx), k1 = big0 + (int)((long long)(ksteps - big0) * (sl + 1) / Sx);
+          of_tile[t].push_back({sl * p + t, 0, t, k0, k1 - k0, nrem + sl, 0});
+        }
+        for (Piece& pc : of_tile[t]) {
+          pc.nslices = (int)of_tile[t].size();
+          pc.slot += xcd * per_xcd_cap;
+          pc.tile = t0 + t;
+          if (pc.round + 1 > tail_rounds) tail_rounds = pc.round + 1;
+          pieces.push_back(pc);
+        }
+      }
+    }
+  }
+  const int rounds = full + tail_rounds;
   const int words = PLAN_HDR + rounds * nwg * 8;
   HERO_REQUIRE(plan && capacity_words >= words, "hero_wgrad_batch_plan: needs %d words, capacity %d", words, capacity_words);
   for (int i = PLAN_HDR; i < words; ++i) plan[i] = 0;
@@ -1148,23 +1220,12 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
       int32_t* q = item(r, w);
       q[0] = t.prob; q[1] = t.mt * G::BM; q[2] = t.nt * G::BN; q[3] = 0; q[4] = ksteps; q[5] = 0; q[6] = 1; q[7] = 0;
     }
-  int S = 1;
-  if (rem) {
-    const int per_xcd_cap = nwg / 8, per_xcd = (rem + 7) / 8;         // tail tiles per XCD
-    S = per_xcd_cap / per_xcd;
-    while (S > 1 && ksteps / S < 4) --S;
-    if (S > 8) S = 8;
-    HERO_REQUIRE(per_xcd <= 512 / 8, "hero_wgrad_batch_plan: flag capacity");
-    for (int j = 0; j < rem; ++j) {
-      const T3& t = tiles[(size_t)full * nwg + j];
-      const int xcd = j / per_xcd, loc = j % per_xcd;
-      for (int sl = 0; sl < S; ++sl) {
-        const int k0 = (int)((long long)ksteps * sl / S), k1 = (int)((long long)ksteps * (sl + 1) / S);
-        int32_t* q = item(full, xcd * per_xcd_cap + sl * per_xcd + loc);
-        q[0] = t.prob; q[1] = t.mt * G::BM; q[2] = t.nt * G::BN; q[3] = k0; q[4] = k1 - k0; q[5] = sl; q[6] = S;
-        q[7] = xcd * (512 / 8) + loc;
-      }
-    }
+  for (const Piece& pc : pieces) {
+    const T3& t = tiles[(size_t)full * nwg + pc.tile];
+    int32_t* q = item(full + pc.round, pc.slot);
+    HERO_REQUIRE(q[4] == 0, "hero_wgrad_batch_plan: internal error (slot used twice)");
+    q[0] = t.prob; q[1] = t.mt * G::BM; q[2] = t.nt * G::BN; q[3] = pc.k0; q[4] = pc.nk; q[5] = pc.order; q[6] = pc.nslices;
+    q[7] = (pc.slot / per_xcd_cap) * (512 / 8) + (pc.tile % per_xcd);
   }
   plan[0] = PLAN_MAGIC; plan[1] = nwg; plan[2] = rounds; plan[3] = rounds * nwg; plan[4] = n; plan[5] = K; plan[6] = T; plan[7] = S;
   return words;

@@ -323,10 +323,33 @@ def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None, colsum=None):
     reduction-contiguous -> the direct-to-LDS GEMM path.  colsum (fp32 [K]) += column sums of dx."""
     M, N = dy2.shape
     K = Wt.shape[0]
+    if (dy2.dtype == torch.bfloat16 and act == L.ACT_NONE and aux is None and residual is None and colsum is None
+            and N >= 8192 and M * K <= (1 << 21)):
+        return _dgrad_long_reduction(dy2, Wt)
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
     k_gemm(dy2, Wt, dx, M, K, N, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.dt(dy2), act=act, aux=aux,
            residual=residual, colsum=colsum)
     return dx
+
+
+def _dgrad_long_reduction(dy2, Wt):
+    """dx = dy2 @ Wt^T where the reduction is tens of thousands long and the output small: the gradient of the MLM
+    vocabulary projection w.r.t. its input, (1440, 50272) x (50272, 768) (model/layers.py:330-354).  One tile per
+    workgroup leaves 72 workgroups walking 786 k-steps each, and 50272 % 64 != 0 sent the whole GEMM to the
+    register-staged fallback (982 us, profiles/r03_kernel_stats_D3.csv).  Here: the 64-aligned part of the reduction
+    split across the chip on the direct-to-LDS kernels (fp32 partial sums), the ragged rest (< 64 columns) as a small
+    accumulate on top, one cast."""
+    M, N = dy2.shape
+    K = Wt.shape[0]
+    n1 = N // 64 * 64
+    out = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+    tiles = -(-M // 128) * -(-K // 128)
+    split = max(1, min(n1 // 64 // 8, 16, -(-512 // tiles)))
+    k_gemm(dy2, Wt, out, M, K, n1, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.BF16, out_f32=True, beta=0.0, split_k=split)
+    if n1 < N:
+        k_gemm(L.ptr(dy2) + 2 * n1, L.ptr(Wt) + 2 * n1, out, M, K, N - n1, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.BF16,
+               out_f32=True, beta=1.0)
+    return k_cast(out, torch.bfloat16)
 
 
 def _split_for(n_out, n_in, rows, bk):

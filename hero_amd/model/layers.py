@@ -23,10 +23,12 @@ class LayerNorm(nn.Module):
         self.eps = eps
         self.normalized_shape = (size,)
 
-    def forward(self, x, dropout=None, out_dtype=None):
+    def forward(self, x, dropout=None, out_dtype=None, tables=(), idxs=(), skip_idx=None):
+        """tables / idxs / skip_idx: embedding rows added to x in front of the normalisation (HF.embed_ln)."""
         shp = x.shape
         y = HF.embed_ln(x, self.weight, self.bias, self.eps, dropout,
-                        out_dtype or (x.dtype if x.dtype == torch.bfloat16 else HF.compute_dtype()))
+                        out_dtype or (x.dtype if x.dtype == torch.bfloat16 else HF.compute_dtype()),
+                        tables=tables, idxs=idxs, skip_idx=skip_idx)
         return y.view(shp)
 
 
@@ -56,10 +58,12 @@ class LinearLayer(nn.Module):
             self.LayerNorm = LayerNorm(in_hsz, eps=1e-5)
         self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, tables=(), idxs=(), skip_idx=None):
         cd = HF.compute_dtype()
         if self.layer_norm:
-            x = self.LayerNorm(x, dropout=_drop(self.net[0], x.device), out_dtype=cd)
+            x = self.LayerNorm(x, dropout=_drop(self.net[0], x.device), out_dtype=cd, tables=tables, idxs=idxs, skip_idx=skip_idx)
+        elif tables:
+            raise NotImplementedError("LinearLayer(layer_norm=False) with embedding tables")
         else:
             if self.net[0].training and self.net[0].p > 0:
                 raise NotImplementedError("LinearLayer(layer_norm=False) with dropout")

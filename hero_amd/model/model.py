@@ -169,7 +169,12 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         matched = self.collect_frame_outputs(shape, f_seq, batch["num_subs"],
                                              batch["sub_idx2frame_idx"], frame_map=batch["frame_map"])
         # ReLU(Linear(drop(LN(c_v_feats)))) + matched, residual fused into the GEMM epilogue
-        fused = self.frame_transform(c_v_feats, residual=matched)
+        # (forward_mfm: + mask_embedding[c_v_masks], model/model.py:244-247, summed inside the LayerNorm kernel)
+        mfm = batch.get("_c_v_mask_rows")
+        if mfm is not None:
+            fused = self.frame_transform(c_v_feats, residual=matched, tables=(self.mask_embedding.weight,), idxs=(mfm,), skip_idx=(0,))
+        else:
+            fused = self.frame_transform(c_v_feats, residual=matched)
         if not encode_clip:
             return HF.cast(fused, torch.float32) if self.output_fp32 else fused
         out = self.c_encoder(clip_level_frame_feat=fused, clip_level_pos_ids=None,
@@ -197,8 +202,11 @@ class HierarchicalVlModel(VideoPreTrainedModel):
         assert loss in ("regression", "nce")
         c_v_mask = batch["c_v_masks"]
         c_v_feats = batch["c_v_feats"]
-        c_v_feats.masked_fill_(c_v_mask.unsqueeze(-1), 0)                 # model/model.py:244
-        batch["c_v_feats"] = c_v_feats + self.mask_embedding(c_v_mask.long())
+        c_v_feats.masked_fill_(c_v_mask.unsqueeze(-1), 0)                 # model/model.py:244 (in place, like the reference)
+        # model/model.py:245-247 rebinds batch['c_v_feats'] = c_v_feats + mask_embedding(c_v_masks) in its LOCAL copy of
+        # the batch dict; here the embedding row is added inside frame_transform's LayerNorm kernel (no 33 MB temporary,
+        # no aten embedding backward: 112 us per MFM micro-step, profiles/r03_kernel_stats_D3.csv), row 0 = padding_idx
+        batch["_c_v_mask_rows"] = HF.memo("c_v_mask_rows", (c_v_mask,), lambda: c_v_mask.reshape(-1).to(torch.int32).contiguous())
         clip_outputs = self.forward_repr(batch)
         pred = self.feat_regress(self._compute_masked_hidden(clip_outputs, c_v_mask))
         neg = self.feat_regress(self._compute_masked_hidden(clip_outputs, c_v_mask, invert=True)) \

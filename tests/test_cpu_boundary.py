@@ -280,11 +280,14 @@ def test_memo_tracks_identity_and_version():
     assert len(calls) == 4
 
 
-@pytest.mark.parametrize("rows,layers,extra", [(12000, 6, ()), (1920, 3, ((768, 4352),)), (12040, 1, ()), (786432, 2, ())])
+@pytest.mark.parametrize("rows,layers,extra", [(12000, 6, ()), (1920, 3, ((768, 4352),)), (12040, 1, ()), (786432, 2, ()),
+                                               (393216, 1, ()), (12000, 1, ((768, 768),) * 3), (4096, 1, ((2304, 768),)), (12000, 5, ())])
 def test_wgrad_batch_plan_covers_every_tile_once(built_lib, rows, layers, extra):
     """hero_wgrad_batch_plan is host code (no GPU): every 192 x 192 tile of every problem appears exactly once per
-    k-step; full rounds hold whole tiles; the k-slices of a tail tile are contiguous, ordered, share one flag and one
-    XCD (workgroup ids w with equal w // (nwg / 8)), and no two tail tiles share a flag."""
+    k-step; full rounds hold whole tiles; the pieces of a tail tile are contiguous in slice order, share one flag and one
+    XCD (workgroup ids w with equal w // (nwg / 8)), no two tail tiles share a flag, a workgroup holds at most one item
+    per round, and (round 4) the tail is BALANCED: no workgroup of an XCD that has tail tiles carries more than its
+    quota of k-steps (+ rounding), so one BertLayer (192 tiles, 24 per XCD) fills all 256 workgroups."""
     from hero_amd import _lib as L
     lib = L.lib()
     shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * layers + list(extra)
@@ -301,17 +304,21 @@ def test_wgrad_batch_plan_covers_every_tile_once(built_lib, rows, layers, extra)
     plan = buf[8:words].reshape(rounds, nwg, 8)
     expect = {(i, a * 192, b * 192) for i, (m, k) in enumerate(shapes) for a in range(-(-m // 192)) for b in range(-(-k // 192))}
     assert tiles == len(expect)
+    full = tiles // nwg
     cover, flags = {}, {}
+    load = np.zeros(nwg, dtype=np.int64)
     for r in range(rounds):
         for w in range(nwg):
             prob, m0, n0, k0, nk, order, nslices, flag = plan[r, w]
             if nk == 0:
-                continue                                      # idle slot of the tail round
+                continue                                      # idle slot of a tail round
             key = (int(prob), int(m0), int(n0))
             assert key in expect
             cover.setdefault(key, []).append((int(order), int(k0), int(nk), int(nslices), r, w, int(flag)))
-            if r < rounds - 1 or tiles % nwg == 0:
+            if r < full:
                 assert (k0, nk, order, nslices) == (0, ksteps, 0, 1)          # a full round: whole tiles, no merge
+            else:
+                load[w] += nk
     assert set(cover) == expect
     for key, parts in cover.items():
         parts.sort()
@@ -319,11 +326,23 @@ def test_wgrad_batch_plan_covers_every_tile_once(built_lib, rows, layers, extra)
         assert parts[0][1] == 0 and sum(p[2] for p in parts) == ksteps
         assert all(a[1] + a[2] == b[1] for a, b in zip(parts, parts[1:]))     # contiguous, in slice order
         if len(parts) > 1:
-            assert len({p[4] for p in parts}) == 1                            # one round
+            assert all(p[4] >= full for p in parts)                           # tail rounds only
             assert len({p[5] // (nwg // 8) for p in parts}) == 1              # one XCD: the merge stays in its L2
             assert len({p[6] for p in parts}) == 1
             assert flags.setdefault(parts[0][6], key) == key                  # a flag per tail tile
-            assert min(p[2] for p in parts) >= 4
+            assert min(p[2] for p in parts) >= 2 and len(parts) <= 10
+    rem = tiles % nwg
+    if rem:
+        per_xcd = -(-rem // 8)
+        for x in range(8):
+            p = min(per_xcd, max(0, rem - x * per_xcd))
+            if p == 0:
+                continue
+            quota = max(4, -(-p * ksteps // (nwg // 8)))
+            xl = load[x * (nwg // 8):(x + 1) * (nwg // 8)]
+            assert xl.sum() == p * ksteps
+            if nwg // 8 // p <= 8:                                            # (beyond the slice cap the slices are just equal)
+                assert xl.max() <= quota + max(4, quota // 8), (x, xl.tolist(), quota)
 
 
 def test_attention_capability_queries(built_lib):

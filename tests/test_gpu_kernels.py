@@ -293,12 +293,14 @@ def _run_batch(Lb, probs, n, rows):
     return buf[:words]
 
 
-@pytest.mark.parametrize("rows,layers", [(1920, 3), (1000, 6), (12000, 6)])
+@pytest.mark.parametrize("rows,layers", [(1920, 3), (1000, 6), (12000, 6), (4096, 1), (2048, 5)])
 def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     """hero_wgrad_batch: the weight gradients of ALL layers of an encoder over the same rows in one launch - whole
     192 x 192 tiles in full rounds (plain fp32 read-add-write), the last partial round cut into k-slices with ordered
     atomics.  (1920, 3) = the Temporal Transformer (576 tiles: 2 rounds + 64 tiles x 4 slices), (12000, 6) = the
-    cross-modal stack of the benched step (1152 tiles: 4 rounds + 128 tiles x 2 slices), 1000 rows: a reduction tail.
+    cross-modal stack of the benched step (1152 tiles: 4 rounds + 128 tiles x 2 slices), 1000 rows: a reduction tail;
+    (4096, 1) / (2048, 5): 192 tail tiles = ONE BertLayer (what config 5's queue cap flushes at a time) - round 4's balanced
+    tail: a 3/4 slice per tile on 192 workgroups, the quarters packed three to a workgroup on the other 64.
     Accumulates into existing values; the result is BIT-REPRODUCIBLE run to run."""
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
     dys, xs, outs, probs = _batch_problems(Lb, rows, layers, shapes)
@@ -313,8 +315,10 @@ def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     assert float((dbs[0] - 0.125).abs().max()) == 0.0
     first_db = [d.clone() for d in dbs]
     assert plan[6] == layers * 192
-    if rows != 12000:
+    if (rows, layers) in ((1920, 3), (1000, 6)):
         assert plan[7] > 1                      # the tail round is sliced
+    if layers in (1, 5):                        # 192 tail tiles (24 per XCD on 32 workgroups): big slices + packed remainders
+        assert plan[2] > layers * 192 // 256 + 1
     first = [o.clone() for o in outs]
     for i in range(n):
         ref = dys[i].float().t() @ xs[i].float() + 0.25
@@ -386,6 +390,18 @@ def test_deferred_weight_gradients_are_flushed_with_the_backward_pass(HF, Lb):
     for w, r in zip(ws, ref_ws):
         assert w.grad is not None
         torch.testing.assert_close(w.grad, r.grad, rtol=5e-2, atol=5e-2 * float(r.grad.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1440, 50272, 768), (360, 8200, 768), (1440, 16384, 136)])
+def test_dgrad_long_reduction_small_output(HF, Lb, M, N, K):
+    """functional._dgrad_long_reduction: dx = dy @ Wt^T with a vocabulary-long reduction (configs[3]: the MLM decoder's
+    input gradient, 50272 % 64 = 32) - split-K on the direct-to-LDS kernels + the ragged rest + a cast, against fp32."""
+    dy = rnd(M, N, dtype=torch.bfloat16, seed=1, scale=0.05)
+    wt = rnd(K, N, dtype=torch.bfloat16, seed=2, scale=0.05)
+    dx = HF.k_dgrad_t(dy, wt)
+    assert dx.dtype == torch.bfloat16 and dx.shape == (M, K)
+    ref = dy.float() @ wt.float().t()
+    close(dx, ref, torch.bfloat16, scale=float(ref.abs().max()))
 
 
 def test_deferred_weight_gradients_same_destination_twice(HF, Lb):

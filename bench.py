@@ -42,7 +42,9 @@ SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (4-wave tiles, K-contiguous operands: t
                  "of the M = 12000 row batch, fused epilogues)",
               9: "gemm_ws_kernel<3,3,O,O> (wave-specialised 192x192 wgrad dY^T X)",
               10: "gemm_ws_kernel<2,3,K,K> (wave-specialised 128x192 tiles: the 1920-row GEMMs with N >= 2304)"}
-PROFILE_TRAFFIC = "r03_pmc_traffic.json"
+PROFILE_TRAFFIC = os.environ.get("HERO_PROFILE_TRAFFIC", "r04_pmc_traffic.json")   # stamped with the kernel-source hash
+PROFILE_MFMA = os.environ.get("HERO_PROFILE_MFMA", "r04_pmc_mfma.json")
+HBM_PEAK_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s achievable)
 
 
 def algorithmic_flops_per_video(sh):
@@ -161,13 +163,16 @@ def _timed(trainer, batch, task, steps, warmup, world):
     return dt, float(loss)
 
 
-def secondary_workload(args, device, world, rank):
-    """The other BASELINE.json configurations as bench lines of their own (same JSON contract, own `metric`)."""
+def secondary_workload(args, device, world, rank, steps=None, warmup=None):
+    """The other BASELINE.json configurations as bench lines of their own (same JSON contract, own `metric`).  Returns the
+    line (a dict); `python bench.py --workload W` prints it, the default D2 run attaches short versions as `secondary`."""
     from hero_amd.step import TrainStep
     from hero_amd.synth import SHAPES, make_batch, make_pretrain_batches
     cfg = json.loads(json.dumps(HERO_BASE))
     graph = not torch.distributed.is_initialized() and not args.no_graph
-    steps, warmup = args.steps + args.steps % 2, args.warmup + args.warmup % 2     # whole accumulation windows
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    steps, warmup = steps + steps % 2, warmup + warmup % 2     # whole accumulation windows
     base = {"unit": "videos/s", "n_gpus": world, "steps": steps, "warmup": warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32",
             "data": "synthetic"}
@@ -263,8 +268,45 @@ def secondary_workload(args, device, world, rank):
                    step_tflops=round(vps / B * fl / 1e12, 1),
                    step_frac_of_bf16_peak=round(vps / B * fl / 1e12 / world / BF16_PEAK_TFLOPS, 4), final_loss=loss,
                    peak_mem_gb=round(peak / 2 ** 30, 2), hbm_frac=round(peak / total, 3))
-    if rank == 0:
-        print(json.dumps(out))
+    return out
+
+
+def feed_run(device, rank, steps, warmup, n_batches=4):
+    """D2 through hero_amd.loader.StaticBatchFeeder: distinct pinned host batches, H2D one step ahead (the PCIe-inclusive
+    rate; never the headline value)."""
+    from hero_amd.loader import StaticBatchFeeder, pin_batch
+    from hero_amd.step import TrainStep
+    from hero_amd.synth import SHAPES, make_batch
+    cfg_path = "/tmp/hero_bench_feed_%d.json" % rank
+    with open(cfg_path, "w") as f:
+        json.dump(HERO_BASE, f)
+    model = build_model(device, cfg_path)
+    trainer = TrainStep(model, use_graph=True, static_usage=True, uniform_shapes=True)
+    host = [pin_batch(make_batch("D2", vfeat_dim=VFEAT, vocab=50272, seed=1 + rank + 100 * i)) for i in range(n_batches)]
+    feeder = StaticBatchFeeder(host[0], device)
+    trainer.prepare(feeder.static)
+    feeder.capture()
+    if not feeder._ready:
+        feeder.prefetch(host[0])
+    k = [0]
+
+    def step():
+        b = feeder.commit()
+        k[0] += 1
+        feeder.prefetch(host[k[0] % len(host)])
+        return trainer.micro_step(b)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(SHAPES["D2"]["videos"] * steps / dt, 2), "unit": "videos/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "warmup": warmup,
+            "input": "%d distinct pinned host batches through StaticBatchFeeder (33 MB of frame features per micro-step over "
+                     "PCIe, copy stream one step ahead)" % n_batches}
 
 
 def main():
@@ -274,6 +316,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1: skip the short D2r / D3 / feed runs attached to the D2 line as `secondary`")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
     ap.add_argument("--workload", default="D2", choices=["D2", "D2r", "D3", "D4"],
@@ -312,7 +356,9 @@ def main():
     from hero_amd.synth import SHAPES, make_batch
     hero_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     if args.workload != "D2":
-        secondary_workload(args, device, world, rank)
+        out = secondary_workload(args, device, world, rank)
+        if rank == 0:
+            print(json.dumps(out))
         if dist_on:
             torch.distributed.destroy_process_group()
         return
@@ -376,6 +422,30 @@ def main():
     try_graph = dist_on and not args.no_graph and os.environ.get("HERO_DP_GRAPH", "1") not in ("", "0")
     eager_ms = dt / args.steps * 1e3
 
+    # ---- N > 1: what the collectives cost, so that the line itself shows that RCCL saw N ranks ---------------------
+    comm = None
+    if dist_on:
+        accum = trainer.opts.gradient_accumulation_steps
+        ones = torch.ones(1, device=device)
+        torch.distributed.all_reduce(ones)                                 # every rank contributes a 1
+        ar_ms = trainer.arena.probe_allreduce_ms(reps=3)                   # the bucketed all-reduce of one optimiser step, alone
+        while trainer.micro % accum:
+            step()
+        trainer.arena.mute = True                                          # same K steps without the gradient exchange
+        try:
+            dt_mute, _ = timed_run()
+        finally:
+            trainer.arena.mute = False
+        mute_ms = dt_mute / args.steps * 1e3
+        comm = {"backend": torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""),
+                "ranks_seen": int(ones.item()), "wire_dtype": trainer.arena.compress or "f32",
+                "buckets": len(trainer.arena.buckets), "payload_mb_per_opt_step": round(trainer.arena.wire_bytes() / 2 ** 20, 1),
+                "allreduce_ms_per_opt_step": round(ar_ms, 3),
+                "eager_ms_per_step": round(eager_ms, 3), "eager_ms_per_step_without_grad_exchange": round(mute_ms, 3),
+                "exposed_ms_per_opt_step": round(max(0.0, eager_ms - mute_ms) * accum, 3),
+                "forward_allgather": "negatives of the VSM loss (3 padded all-gathers per micro-step, in both runs)",
+                "graph_ms_per_step": None}
+
     # ---- roofline leg: HIP events around every GEMM launch over extra, identical steps ----------
     roof = None
     if rank == 0:
@@ -396,13 +466,13 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS if slot >= 4 else 157.3      # slots 0-3 are the fp32 parity-mode kernels
             traffic, tsrc = None, None
+            want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
+                    7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws",
+                    10: "gemm_ws_kernel<2, 3, false"}.get(slot)
             try:                                   # HBM bytes per launch from the committed PMC passes, stamped with the
                 pj = os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)     # kernel sources they were taken with
                 pm = json.load(open(pj))
                 meta = pm.pop("_meta", {})
-                want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
-                        7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws",
-                        10: "gemm_ws_kernel<2, 3, false"}.get(slot)
                 hits = [v for k, v in pm.items() if want and want in k and (slot != 9 or ", false," not in k)]
                 if hits:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -415,11 +485,30 @@ def main():
                                                                   "the sources of this build" if same else "NOT this build's sources (stale)"))
             except Exception:
                 pass
+            # north_star: "rocprof-reported HBM GB/s and MFMA utilisation against chip peak" - counters cannot be read
+            # inside the run, so both come from the committed PMC passes of the same command (stamped like `traffic`):
+            # HBM bytes per launch / this run's live launch duration, and SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x
+            # GPU-active cycles), launch-weighted over the family's instantiations.
+            hbm_gbps = mfma_busy = None
+            if traffic:
+                hbm_gbps = traffic / (ms * 1e-3 / n) / 1e9
+            try:
+                mm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_MFMA)))
+                mm.pop("_meta", None)
+                mh = [v for k, v in mm.items() if want and want in k and (slot != 9 or ", false," not in k)]
+                if mh:
+                    mfma_busy = sum(h["mfma_util"] * h["launches"] for h in mh) / sum(h["launches"] for h in mh)
+            except Exception:
+                pass
             roof = {"bound": "mfma", "kernel": SLOT_NAMES.get(slot, "gemm slot %d" % slot),
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "launches": n,
                     "avg_launch_us": round(ms * 1e3 / n, 2),
-                    "flops_per_launch": fl / n}
+                    "flops_per_launch": fl / n,
+                    "hbm_gbps": round(hbm_gbps, 1) if hbm_gbps else None,
+                    "hbm_frac_of_peak": round(hbm_gbps / HBM_PEAK_GBPS, 4) if hbm_gbps else None,
+                    "mfma_busy": round(mfma_busy, 4) if mfma_busy is not None else None,
+                    "counters_source": "profiles/%s + profiles/%s (rocprofv3 --pmc passes of this command)" % (PROFILE_TRAFFIC, PROFILE_MFMA)}
     elif world > 1:
         for _ in range(args.profile_steps):
             trainer.micro_step(batch)
@@ -449,6 +538,7 @@ def main():
             "final_loss": loss_,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "comm": comm,
         }
 
     out = line(dt, loss_val, "hipGraph replay" if graph_mode else "eager")
@@ -473,7 +563,11 @@ def main():
             while trainer.micro % trainer.opts.gradient_accumulation_steps:     # odd --steps / --warmup: finish the window
                 step()
             trainer.enable_graph(collectives=True)
+            if os.environ.get("HERO_DP_GRAPH_TEST_WEDGE"):      # test hook: a captured run that never comes back
+                time.sleep(1e6)
             dt_g, loss_g = timed_run()
+            if comm is not None:
+                comm["graph_ms_per_step"] = round(dt_g / args.steps * 1e3, 3)
             if dt_g < dt and loss_g == loss_g:
                 out = line(dt_g, loss_g, "hipGraph replay (step captured with its RCCL collectives)")
                 out["config"]["eager_ms_per_step"] = round(eager_ms, 3)
@@ -484,6 +578,27 @@ def main():
             hard_exit = True                         # the process group may be unusable: no orderly teardown
         finished.set()
         timer.cancel()
+    # ---- N = 1: the other configurations ride on the line (short runs, after everything that is timed above) -------
+    if rank == 0 and world == 1 and not dist_on and not args.no_secondary and not args.feed:
+        del trainer, model, batch
+        torch.cuda.empty_cache()
+        sec, t_sec = {}, time.perf_counter()
+        ns = argparse.Namespace(**vars(args))
+        for w in ("D2r", "D3"):
+            try:
+                ns.workload = w
+                r = secondary_workload(ns, device, world, rank, steps=6, warmup=2)
+                sec[w] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "per_task") if k in r}
+                sec[w]["launch"] = r["config"]["launch"]
+            except Exception as e:                       # noqa: BLE001 - a secondary line never takes the headline down
+                sec[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            torch.cuda.empty_cache()
+        try:
+            sec["feed"] = feed_run(device, rank, steps=12, warmup=4)
+        except Exception as e:                           # noqa: BLE001
+            sec["feed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        sec["wall_s"] = round(time.perf_counter() - t_sec, 1)
+        out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if hard_exit:

@@ -19,7 +19,7 @@ EXPORTS = [
     "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok",
-    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
+    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
     "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
@@ -197,6 +197,13 @@ def lib():
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hero_scatter_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hero_segment_sort_workspace_bytes.argtypes = [C.c_int]
+        L.hero_segment_sort_workspace_bytes.restype = C.c_size_t
+        L.hero_segment_sort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hero_scatter_add_sorted_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        L.hero_scatter_add_sorted_workspace_bytes.restype = C.c_size_t
+        L.hero_scatter_add_sorted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p]
         L.hero_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.hero_transpose_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]

@@ -1156,18 +1156,19 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
     HERO_REQUIRE(per_xcd <= 512 / 8, "hero_wgrad_batch_plan: flag capacity");
     for (int xcd = 0; xcd * per_xcd < rem; ++xcd) {
       const int t0 = xcd * per_xcd, p = (rem - t0 < per_xcd) ? rem - t0 : per_xcd, c = per_xcd_cap;
-      int q = (int)(((long long)p * ksteps + c - 1) / c);
-      if (q < 4) q = 4;
+      // equal slices first (round 3's rule: at least 4 k-steps per slice, at most 8 slices - every slice adds a tile of atomics)
       int Sx = c / p;
-      if (Sx > ksteps / q) Sx = ksteps / q;
+      while (Sx > 1 && ksteps / Sx < 4) --Sx;
       if (Sx > 8) Sx = 8;
-      if (Sx < 1) Sx = 1;
-      int L = c - Sx * p;
+      const int L = c - Sx * p;
+      // workgroups left over (c / p not whole) take the remainders - where the reduction is long enough that a piece's own
+      // epilogue (a tile of atomics, ~4 k-steps' worth) does not eat the gain: ksteps >= 128, pieces of >= 4 steps
+      // (a piece costs its k-steps + E for its own epilogue, so the quota q solves p (ksteps - Sx q + E) = L (q + E); worth
+      // it only where the remainders are a real share of a tile - 30 tail tiles on 32 workgroups stay as they are)
+      const int E = 6;
+      int q = (int)(((long long)p * ksteps + (long long)(p - L) * E + c - 1) / c);
       int r = ksteps - Sx * q;
-      if (r < 0) r = 0;
-      // no free workgroup / nothing worth a piece / the slice cap already reached (every slice adds a tile of atomics):
-      // equal big slices only
-      if (L == 0 || r < 2 || (Sx == 8 && c / p > 8)) r = 0;
+      if (L == 0 || Sx != c / p || ksteps < 128 || r * 8 < ksteps) { r = 0; q = ksteps; }
       if (xcd == 0) S = Sx;
       // remainder pieces: walk the free workgroups
       std::vector<std::vector<Piece>> of_tile(p);

@@ -66,6 +66,192 @@ __global__ void scatter_add_rows_kernel(const TS* __restrict__ src, const int32_
   }
 }
 
+// ---- deterministic embedding-table gradients: sort the rows by destination, one owner per destination ----------
+// dst[idx[r]] += src[r] with fp32 atomics depends on the order the atomics land in as soon as a destination receives
+// three or more rows (frequent tokens: every real batch; ~100 ids of the synthetic one) - the last kernel of the 1-GPU
+// step whose result was not reproducible run to run.  Instead:
+//   segment_sort_kernel   ONE workgroup, stable LSD radix sort (4-bit digits) of (destination, row) pairs: 1024 threads own
+//                         contiguous chunks of the list, count their 16 digits, an exclusive scan over [digit][thread]
+//                         gives every thread its write positions, elements move in chunk order (stable).  The list is
+//                         ~10^4 ids per micro-step (10^6 at config 5: ~1 ms of a 600 ms step); it is sorted once per
+//                         batch object (functional.memo) and refreshed with the batch by the feeder's commit graph.
+//   scatter_sorted_kernel one wave per sorted position; the head of a run of equal destinations sums the run's source
+//                         rows in row order (fp32) and adds the sum to the table row it alone owns - no atomics.
+constexpr int SORT_NT = 1024;
+__global__ __launch_bounds__(SORT_NT) void segment_sort_kernel(const int32_t* __restrict__ idx, int rows, int skip, int nbits,
+                                                               uint2* __restrict__ buf0, uint2* __restrict__ buf1,
+                                                               int32_t* __restrict__ order) {
+  extern __shared__ uint32_t hist[];                 // [16][SORT_NT] counters / offsets, then [32] wave totals
+  uint32_t* wsum = hist + 16 * SORT_NT;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int cpt = (rows + SORT_NT - 1) / SORT_NT;
+  const int beg = min(t * cpt, rows), end = min(beg + cpt, rows);
+  const uint32_t last_key = (1u << nbits) - 1u;      // dropped rows (idx < 0 or == skip) sort behind every real destination
+  for (int i = beg; i < end; ++i) {
+    const int v = idx[i];
+    buf0[i] = make_uint2((v < 0 || v == skip) ? last_key : (uint32_t)v, (uint32_t)i);
+  }
+  __syncthreads();
+  uint2* src = buf0;
+  uint2* dst = buf1;
+  for (int shift = 0; shift < nbits; shift += 4) {
+    uint32_t cnt[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) cnt[b] = 0;
+    for (int i = beg; i < end; ++i) {
+      const uint32_t d = (src[i].x >> shift) & 15u;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) cnt[b] += (d == (uint32_t)b);
+    }
+#pragma unroll
+    for (int b = 0; b < 16; ++b) hist[b * SORT_NT + t] = cnt[b];
+    __syncthreads();
+    // exclusive scan of the flattened [digit][thread] array: thread t owns entries 16 t .. 16 t + 15
+    uint32_t loc[16], run = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { loc[k] = run; run += hist[16 * t + k]; }
+    uint32_t inc = run;                               // inclusive scan of `run` over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = inc - run;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hist[16 * t + k] = base + loc[k];
+    __syncthreads();
+    uint32_t pos[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) pos[b] = hist[b * SORT_NT + t];
+    for (int i = beg; i < end; ++i) {
+      const uint2 e = src[i];
+      const uint32_t d = (e.x >> shift) & 15u;
+      uint32_t at = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b)
+        if (d == (uint32_t)b) { at = pos[b]; pos[b] += 1; }
+      dst[at] = e;
+    }
+    __syncthreads();                                   // (global writes of this workgroup are visible to it behind the barrier)
+    uint2* tmp = src; src = dst; dst = tmp;
+  }
+  for (int i = t; i < rows; i += SORT_NT) order[i] = (int32_t)src[i].y;
+}
+
+// Blocks of SEG_B sorted positions, one wave each.  A run of equal destinations that lies inside one block is summed and
+// added to its table row by that wave (the row has no other writer).  A run that crosses block boundaries - the SEP
+// token heads every subtitle: 480 rows of the TVR batch go to ONE table row - leaves one partial sum per block in the
+// workspace (slot 0: the block's first run continues from the previous block, slot 1: its last run continues into the
+// next one), and the second kernel lets the wave of the run's FIRST block add the partials up in block order.
+constexpr int SEG_B = 32;
+__device__ __forceinline__ int seg_key(const int32_t* idx, const int32_t* order, int i, int rows, int skip) {
+  if (i < 0 || i >= rows) return -2;
+  const int v = idx[order[i]];
+  return (v < 0 || v == skip) ? -1 : v;
+}
+
+template <typename TS, int NCH>    // NCH chunks of 256 columns per lane pass (cols <= NCH * 256 per outer iteration)
+__global__ __launch_bounds__(256) void scatter_sorted_kernel(const TS* __restrict__ src, const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ order, float* __restrict__ dst,
+                                                             float* __restrict__ partial, int rows, int cols, int skip) {
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int base = blk * SEG_B;
+  if (base >= rows) return;
+  const int n = min(SEG_B, rows - base);
+  // lane p < n: row number and key of sorted position base + p
+  const int my_row = lane < n ? order[base + lane] : 0;
+  int my_key = -2;
+  if (lane < n) { const int v = idx[my_row]; my_key = (v < 0 || v == skip) ? -1 : v; }
+  const int prev_key = seg_key(idx, order, base - 1, rows, skip), next_key = seg_key(idx, order, base + n, rows, skip);
+  for (int c0 = 0; c0 < cols; c0 += NCH * 256) {
+    float4 acc[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int seg_start = 0;
+    for (int p0 = 0; p0 < n; p0 += 4) {
+      // four rows in flight (the loads of a row only depend on the shuffled row number)
+      float4 v[4][NCH];
+      int keys[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = min(p0 + u, n - 1);
+        keys[u] = __shfl(my_key, p, 64);
+        const int r = __shfl(my_row, p, 64);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          const int c = min(c0 + k * 256 + lane * 4, cols - 4);
+          v[u][k] = V4<TS>::ld(src + (size_t)r * cols + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u;
+        if (p < n) {
+          const int key = keys[u];
+          const int key_next = p + 1 < n ? __shfl(my_key, p + 1, 64) : -3;
+          if (key >= 0) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { acc[k].x += v[u][k].x; acc[k].y += v[u][k].y; acc[k].z += v[u][k].z; acc[k].w += v[u][k].w; }
+          }
+          if (key_next != key) {                         // the run [seg_start, p] ends here (inside the block or at its end)
+            if (key >= 0) {
+              const bool left_open = seg_start == 0 && prev_key == key;
+              const bool right_open = p == n - 1 && next_key == key;
+              float* out = (!left_open && !right_open) ? dst + (size_t)key * cols
+                                                       : partial + ((size_t)blk * 2 + (left_open ? 0 : 1)) * cols;
+#pragma unroll
+              for (int k = 0; k < NCH; ++k) {
+                const int c = c0 + k * 256 + lane * 4;
+                if (c < cols) {
+                  float4* d = reinterpret_cast<float4*>(out + c);
+                  float4 o = acc[k];
+                  if (!left_open && !right_open) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                  *d = o;
+                }
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            seg_start = p + 1;
+          }
+        }
+      }
+    }
+  }
+}
+
+// the wave of the block in which a multi-block run STARTS folds the run's partial sums in block order
+__global__ __launch_bounds__(256) void scatter_sorted_fold_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ order,
+                                                                  float* __restrict__ dst, const float* __restrict__ partial,
+                                                                  int rows, int cols, int skip) {
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int base = blk * SEG_B;
+  if (base >= rows) return;
+  const int n = min(SEG_B, rows - base);
+  const int last = seg_key(idx, order, base + n - 1, rows, skip);
+  if (last < 0 || seg_key(idx, order, base + n, rows, skip) != last) return;        // the last run does not continue
+  // it continues; is this block the run's first?  (not if the whole block is the run and it came in from the left)
+  const bool whole = seg_key(idx, order, base, rows, skip) == last;
+  if (whole && seg_key(idx, order, base - 1, rows, skip) == last) return;
+  const int nblk = (rows + SEG_B - 1) / SEG_B;
+  for (int c = lane * 4; c < cols; c += 256) {
+    float4 acc = *reinterpret_cast<const float4*>(partial + ((size_t)blk * 2 + 1) * cols + c);
+    for (int b = blk + 1; b < nblk; ++b) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)b * 2 + 0) * cols + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      const int e = min(b * SEG_B + SEG_B, rows);
+      if (seg_key(idx, order, e - 1, rows, skip) != last || seg_key(idx, order, e, rows, skip) != last) break;   // the run ends in block b
+    }
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)last * cols + c);
+    float4 o = *d;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *d = o;
+  }
+}
+
 // ---- elementwise -------------------------------------------------------------------------------------
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, size_t n) {
@@ -383,6 +569,50 @@ extern "C" int hero_scatter_add_rows(const void* src, const int32_t* idx, void* 
     hipLaunchKernelGGL((scatter_add_rows_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, idx, (bf16_t*)dst_a, (bf16_t*)dst_b, rows, cols, skip);
   else { set_error("hero_scatter_add_rows: unsupported dtypes %d -> %d", src_dtype, dst_dtype); return HERO_ERR_UNSUPPORTED; }
   return check_launch("hero_scatter_add_rows");
+}
+
+extern "C" size_t hero_segment_sort_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * 2 * sizeof(uint2); }
+
+extern "C" int hero_segment_sort(const int32_t* idx, int rows, int n_dst, int skip_idx, int32_t* order, void* workspace,
+                                 hero_stream_t stream) {
+  HERO_REQUIRE(idx && order && workspace, "hero_segment_sort: null pointer");
+  HERO_REQUIRE(n_dst > 0 && n_dst < (1 << 30), "hero_segment_sort: n_dst = %d", n_dst);
+  if (rows <= 0) return HERO_OK;
+  int nbits = 1;
+  while ((1 << nbits) <= n_dst) ++nbits;              // keys 0 .. n_dst - 1 and the all-ones key of the dropped rows
+  nbits = (nbits + 3) & ~3;
+  static bool attr_set = false;
+  const int lds = (16 * SORT_NT + 32) * (int)sizeof(uint32_t);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&segment_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  uint2* b0 = static_cast<uint2*>(workspace);
+  hipLaunchKernelGGL(segment_sort_kernel, dim3(1), dim3(SORT_NT), lds, static_cast<hipStream_t>(stream), idx, rows,
+                     skip_idx >= 0 ? skip_idx : -1, nbits, b0, b0 + rows, order);
+  return check_launch("hero_segment_sort");
+}
+
+extern "C" size_t hero_scatter_add_sorted_workspace_bytes(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return (size_t)((rows + SEG_B - 1) / SEG_B) * 2 * (size_t)cols * sizeof(float);
+}
+
+extern "C" int hero_scatter_add_sorted(const void* src, const int32_t* idx, const int32_t* order, float* dst, int rows, int cols,
+                                       int src_dtype, int skip_idx, void* workspace, hero_stream_t stream) {
+  HERO_REQUIRE(src && idx && order && dst && workspace, "hero_scatter_add_sorted: null pointer");
+  HERO_REQUIRE(cols > 0 && cols % 4 == 0, "hero_scatter_add_sorted: cols (%d) must be a multiple of 4", cols);
+  if (rows <= 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nblk = (rows + SEG_B - 1) / SEG_B, grid = (nblk + 3) / 4, skip = skip_idx >= 0 ? skip_idx : -1;
+  float* part = static_cast<float*>(workspace);
+  if (src_dtype == HERO_BF16) hipLaunchKernelGGL((scatter_sorted_kernel<bf16_t, 3>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, idx, order, dst, part, rows, cols, skip);
+  else if (src_dtype == HERO_F32) hipLaunchKernelGGL((scatter_sorted_kernel<float, 3>), dim3(grid), dim3(256), 0, s, (const float*)src, idx, order, dst, part, rows, cols, skip);
+  else { set_error("hero_scatter_add_sorted: bad dtype %d", src_dtype); return HERO_ERR_ARG; }
+  int rc = check_launch("hero_scatter_add_sorted");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scatter_sorted_fold_kernel, dim3(grid), dim3(256), 0, s, idx, order, dst, part, rows, cols, skip);
+  return check_launch("hero_scatter_add_sorted(fold)");
 }
 
 extern "C" int hero_cast(const void* src, void* dst, size_t n, int sd, int dd, hero_stream_t stream) {

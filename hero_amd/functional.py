@@ -387,6 +387,7 @@ def _split_for(n_out, n_in, rows, bk):
 # count changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
 # pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
 # The queue keeps dY / X alive until then (~1 GB for HERO-base at 12000 rows).
+DETERMINISTIC_SCATTER = [os.environ.get("HERO_ATOMIC_SCATTER", "") == ""]    # HERO_ATOMIC_SCATTER=1: the fp32-atomic embedding scatter of rounds 1-3 (A/B)
 _WQ = []
 _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [os.environ.get("HERO_NOGROUP", "") == ""]      # HERO_NOGROUP=1: one launch per weight gradient (A/B runs)
@@ -726,6 +727,26 @@ def k_scatter_add(src2, idx, dst_a, dst_b=None, skip=-1):
                                           cols, L.dt(src2), L.dt(dst_a), skip, L.stream()))
 
 
+def segment_order(idx, n_dst, skip=-1):
+    """Rows sorted by destination (hero_segment_sort), cached per index tensor like every derived batch tensor (memo:
+    the same batch object runs several micro-steps; refresh_memo redoes it when new ids are written into the buffers)."""
+    def build():
+        order = torch.empty(idx.numel(), dtype=torch.int32, device=idx.device)
+        ws = torch.empty(max(L.lib().hero_segment_sort_workspace_bytes(idx.numel()) // 4, 1), dtype=torch.int32, device=idx.device)
+        L.check(L.lib().hero_segment_sort(L.ptr(idx), idx.numel(), n_dst, skip, L.ptr(order), L.ptr(ws), L.stream()))
+        return order
+    return memo("seg_order", (idx,), build, (n_dst, skip))
+
+
+def k_scatter_add_sorted(src2, idx, dst, skip=-1):
+    """dst[idx[r]] += src2[r] without atomics, bit-reproducible (embedding-table gradients); dst fp32 [n_dst, cols]."""
+    rows, cols = src2.shape
+    order = segment_order(idx, dst.shape[0], skip)
+    ws = _workspace(L.lib().hero_scatter_add_sorted_workspace_bytes(rows, cols) // 4, src2.device, slot="scatter_sorted")
+    L.check(L.lib().hero_scatter_add_sorted(L.ptr(src2), L.ptr(idx), L.ptr(order), L.ptr(dst), rows, cols, L.dt(src2), skip,
+                                            L.ptr(ws), L.stream()))
+
+
 def k_cast(x, dtype):
     if x.dtype == dtype:
         return x
@@ -778,22 +799,33 @@ def refresh_memo(sources=None):
     captured graphs and cached maps hold the derived tensors by address.  sources: only the entries derived from one
     of these tensors (default: every entry).  Entries with a `spec` go out together as hero_derive_multi launches."""
     ptrs = None if sources is None else {t.data_ptr() for t in sources}
-    batch = []
-    for out, srcs, fn, spec in list(_MEMO.values()):
-        if ptrs is not None and not any(t.data_ptr() in ptrs for t in srcs):
+    batch, later = [], []
+    entries = list(_MEMO.values())
+    # entries a hero_derive_multi launch computes (functions of ONE raw int64 batch tensor) first, then the entries with a
+    # builder of their own, which may be derived from those (segment_order sorts int32 row indices that are themselves
+    # derived from the batch's ids): a refreshed entry's output counts as a source for the entries behind it
+    for out, srcs, fn, spec in entries:
+        if spec is None or (ptrs is not None and not any(t.data_ptr() in ptrs for t in srcs)):
             continue
-        if spec is not None:
-            batch.append(L.Derive(L.ptr(srcs[0]), L.ptr(out), out.numel(), spec[0], spec[1], spec[2], spec[3]))
+        batch.append(L.Derive(L.ptr(srcs[0]), L.ptr(out), out.numel(), spec[0], spec[1], spec[2], spec[3]))
+        if ptrs is not None:
+            ptrs.add(out.data_ptr())
+    for out, srcs, fn, spec in entries:
+        if spec is not None or (ptrs is not None and not any(t.data_ptr() in ptrs for t in srcs)):
             continue
+        later.append((out, fn))
+        if ptrs is not None and isinstance(out, torch.Tensor):
+            ptrs.add(out.data_ptr())
+    for i in range(0, len(batch), 16):
+        part = batch[i:i + 16]
+        L.check(L.lib().hero_derive_multi((L.Derive * len(part))(*part), len(part), L.stream()))
+    for out, fn in later:
         new = fn()
         if isinstance(out, torch.Tensor):
             if new.shape != out.shape:
                 raise RuntimeError("refresh_memo: a derived tensor changed shape %s -> %s; the batch structure is "
                                    "different, not just its contents" % (tuple(out.shape), tuple(new.shape)))
             out.copy_(new)
-    for i in range(0, len(batch), 16):
-        part = batch[i:i + 16]
-        L.check(L.lib().hero_derive_multi((L.Derive * len(part))(*part), len(part), L.stream()))
 
 
 def as_mask_add(mask, S, Lq):
@@ -996,6 +1028,9 @@ class EmbedLnFn(torch.autograd.Function):
                     # column sum over [S, period*D], then scatter `period` rows - not S-way contended atomics
                     folded = k_colsum(dx.view(dx.shape[0] // per, per * dx.shape[1]))
                     k_scatter_add(folded.view(per, dx.shape[1]), idx[:per], SINK.dst(tab), None, skip)
+                elif (DETERMINISTIC_SCATTER[0] and idx.dtype == torch.int32 and idx.is_contiguous() and dx.shape[1] % 4 == 0
+                        and dx.shape[0] <= (1 << 17)):      # (beyond: a 6 KB-per-32-rows workspace; config 5 keeps the atomics)
+                    k_scatter_add_sorted(dx, idx.view(-1), SINK.dst(tab).view(-1, tab.shape[-1]), skip)
                 else:
                     k_scatter_add(dx, idx, SINK.dst(tab), None, skip)
                 SINK.done(tab)
@@ -1302,9 +1337,14 @@ class FfnBlockFn(torch.autograd.Function):
         if fuse_b:
             SINK.done(b2)
         acc_linear_grads(dy2d, hg, w2, None if fuse_b else b2)
-        fuse_b1 = b1.requires_grad
-        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u,       # * gelu'(u), fused; db1 = column sums of du
-                       colsum=SINK.dst(b1) if fuse_b1 else None)   # from the same epilogue
+        # db1 = column sums of du.  Round 4: they ride on the batched weight-gradient launch (hero_wgrad_batch takes them from
+        # the du panels it streams anyway, in a fixed order) instead of fp32 atomics from this GEMM's epilogue - one of the
+        # two places that made a step's result depend on the order atomics landed in.  Only where the weight gradients go
+        # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
+        # would be a 74 MB column-sum launch per layer.
+        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0])
+        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u,       # * gelu'(u), fused
+                       colsum=SINK.dst(b1) if fuse_b1 else None)
         acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)
         if fuse_b1:
             SINK.done(b1)

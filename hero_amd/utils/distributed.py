@@ -154,6 +154,7 @@ class GradArena(HF.GradSink):
         # in the previous step, so a bucket that also holds never-used parameters (pooler, lm_head,
         # ...) is still all-reduced as soon as its used gradients are final instead of in finish().
         self.static_usage = static_usage
+        self.mute = False            # measurement switch (bench.py): the same steps WITHOUT the gradient exchange
         self._expect = None
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
@@ -216,7 +217,7 @@ class GradArena(HF.GradSink):
         if p in self._final or p not in self.bucket_of:
             return
         self._final.add(p)
-        if not (self.sync and self.overlap) or not collectives_active():
+        if not (self.sync and self.overlap) or not collectives_active() or self.mute:
             return
         b = self.bucket_of[p]
         if self._expect is not None and p not in self._expect:
@@ -261,7 +262,7 @@ class GradArena(HF.GradSink):
 
     def finish(self):
         """Issue all-reduces for buckets the hooks did not complete, then wait for everything."""
-        if collectives_active() and self.sync:
+        if collectives_active() and self.sync and not self.mute:
             for b in range(len(self.buckets)):
                 self._launch(b)
             for h, b in self._handles:
@@ -286,6 +287,31 @@ class GradArena(HF.GradSink):
 
     def scale_(self, factor):
         self.flat.mul_(factor)
+
+    def wire_bytes(self):
+        """Bytes one optimiser step puts on the wire per rank (before the collective algorithm's own factor)."""
+        per = 2 if self.compress == "bf16" else 4
+        return sum((e - s) * per for s, e, _ in self.buckets)
+
+    def probe_allreduce_ms(self, reps=3):
+        """Time the bucketed all-reduce of one optimiser step ALONE (no backward to hide behind), on scratch buffers of
+        the wire dtype and bucket sizes: what the exchange costs when nothing overlaps it.  Collective on every rank."""
+        if not collectives_active():
+            return 0.0
+        dt = torch.bfloat16 if self.compress == "bf16" else torch.float32
+        bufs = [torch.zeros(e - s, dtype=dt, device=self.flat.device) for s, e, _ in self.buckets]
+        times = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hs = [dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True) for b in bufs]
+            for h in hs:
+                h.wait()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        return sorted(times[1:])[len(times[1:]) // 2]
 
     def zero(self):
         self.flat.zero_()

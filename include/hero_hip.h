@@ -246,6 +246,22 @@ int hero_csr_gather_sum(const void* src, const int32_t* offsets, const int32_t* 
 /* Two destinations as in hero_gather_rows when b != NULL.                                      */
 int hero_scatter_add_rows(const void* src, const int32_t* idx, void* dst_a, void* dst_b, int rows,
                           int cols, int src_dtype, int dst_dtype, int skip_idx, hero_stream_t stream);
+/* The same sum WITHOUT atomics, bit-reproducible (nn.Embedding backward into the fp32 gradient of word_embeddings,    */
+/* model/embed.py:15-18, 28-58: destinations that receive three or more rows make the atomic version order-dependent): */
+/*   hero_segment_sort        order[rows] = the row numbers sorted by (idx[row], row), rows with idx < 0 or == skip_idx */
+/*                            last; one workgroup, stable radix sort; n_dst = rows of the table (bounds the key width); */
+/*                            workspace of hero_segment_sort_workspace_bytes(rows) bytes.  Depends on idx only: cache it. */
+/*   hero_scatter_add_sorted  blocks of 32 sorted rows, one wave each: a run of equal destinations inside a block is   */
+/*                            added to dst[idx] by that wave (row order, fp32; the row has no other writer); a run that */
+/*                            crosses blocks (a token at the head of every subtitle) leaves one partial sum per block   */
+/*                            and the wave of its first block folds them in block order.  dst is fp32; cols % 4 == 0;   */
+/*                            workspace of hero_scatter_add_sorted_workspace_bytes(rows, cols) bytes.                    */
+size_t hero_segment_sort_workspace_bytes(int rows);
+size_t hero_scatter_add_sorted_workspace_bytes(int rows, int cols);
+int hero_segment_sort(const int32_t* idx, int rows, int n_dst, int skip_idx, int32_t* order, void* workspace,
+                      hero_stream_t stream);
+int hero_scatter_add_sorted(const void* src, const int32_t* idx, const int32_t* order, float* dst, int rows, int cols,
+                            int src_dtype, int skip_idx, void* workspace, hero_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Elementwise                                                                                  */

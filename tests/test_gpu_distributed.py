@@ -42,6 +42,11 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 64 and out["config"]["launch"].startswith(("eager", "hipGraph replay (step captured"))
     assert out["final_loss"] == out["final_loss"] and out["roofline"]["frac"] > 0      # finite loss, GEMM events recorded
+    # the line is self-describing: how many ranks the collective saw, what the exchange costs alone, what of it is exposed
+    c = out["comm"]
+    assert c["ranks_seen"] == 2 and c["backend"].startswith("gloo") and c["wire_dtype"] == "bf16" and c["buckets"] > 3
+    assert c["allreduce_ms_per_opt_step"] > 0 and c["eager_ms_per_step"] > 0 and c["eager_ms_per_step_without_grad_exchange"] > 0
+    assert c["exposed_ms_per_opt_step"] >= 0 and 200 < c["payload_mb_per_opt_step"] < 260          # 121 M parameters x 2 B
 
 
 @pytest.mark.parametrize("wire", ["none", "bf16"])
@@ -96,3 +101,19 @@ def test_bench_one_rank_over_rccl_captured_in_a_hipgraph():
     assert g["final_loss"] == g["final_loss"]
     print("RCCL one rank:", g["config"]["launch"], g["ms_per_step"], {k: v for k, v in g["config"].items() if k.endswith("_ms_per_step")})
     assert g["config"]["launch"].startswith("hipGraph replay (step captured") and g["config"]["eager_ms_per_step"] >= g["ms_per_step"]
+
+
+def test_bench_wedged_capture_falls_back_to_the_eager_line():
+    """the captured-collectives run is a second, optional measurement - if it never comes back
+    (HERO_DP_GRAPH_TEST_WEDGE simulates a wedged collective) the watchdog prints the eager line, which already carries
+    the `comm` block, and every rank leaves with exit code 0 so that the launcher does not hang."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1",
+               HERO_DP_GRAPH_TEST_WEDGE="1", HERO_DP_GRAPH_TIMEOUT="5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29557", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "timed out" in out["config"]["launch"] and out["config"]["launch"].startswith("eager")
+    assert out["value"] > 0 and out["comm"]["ranks_seen"] == 1 and out["comm"]["graph_ms_per_step"] is None

@@ -293,13 +293,13 @@ def _run_batch(Lb, probs, n, rows):
     return buf[:words]
 
 
-@pytest.mark.parametrize("rows,layers", [(1920, 3), (1000, 6), (12000, 6), (4096, 1), (2048, 5)])
+@pytest.mark.parametrize("rows,layers", [(1920, 3), (1000, 6), (12000, 6), (8192, 1), (8200, 5)])
 def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     """hero_wgrad_batch: the weight gradients of ALL layers of an encoder over the same rows in one launch - whole
     192 x 192 tiles in full rounds (plain fp32 read-add-write), the last partial round cut into k-slices with ordered
     atomics.  (1920, 3) = the Temporal Transformer (576 tiles: 2 rounds + 64 tiles x 4 slices), (12000, 6) = the
     cross-modal stack of the benched step (1152 tiles: 4 rounds + 128 tiles x 2 slices), 1000 rows: a reduction tail;
-    (4096, 1) / (2048, 5): 192 tail tiles = ONE BertLayer (what config 5's queue cap flushes at a time) - round 4's balanced
+    (8192, 1) / (8200, 5): 192 tail tiles, >= 128 k-steps = ONE BertLayer (what config 5's queue cap flushes at a time) - round 4's balanced
     tail: a 3/4 slice per tile on 192 workgroups, the quarters packed three to a workgroup on the other 64.
     Accumulates into existing values; the result is BIT-REPRODUCIBLE run to run."""
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
@@ -775,6 +775,35 @@ def test_gather_scatter(HF, dtype):
     keep = li.clamp(min=0) != 5
     rt.index_add_(0, li.clamp(min=0)[keep], src.float()[keep])
     torch.testing.assert_close(tab, rt, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,n_dst,cols,dtype", [(9600, 50272, 768, torch.bfloat16), (1300, 37, 768, torch.float32),
+                                                   (70000, 50272, 64, torch.bfloat16), (257, 2, 4352, torch.float32)])
+def test_scatter_add_sorted_is_exact_and_reproducible(HF, Lb, rows, n_dst, cols, dtype):
+    """hero_segment_sort + hero_scatter_add_sorted (round 4): embedding-table gradients without atomics.  The order is
+    the stable sort of the rows by destination (dropped rows last); the sums equal index_add_ of the same rows and are
+    bit-identical run to run, also with destinations that receive hundreds of rows (which the atomic version is not)."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    idx = torch.randint(0, n_dst, (rows,), device="cuda", generator=g, dtype=torch.int32)
+    idx[::7] = 5 % n_dst                                   # a frequent token
+    idx[1::11] = 1 % n_dst                                 # the padding id: skipped
+    idx[2::13] = -1                                        # dropped rows
+    skip = 1 % n_dst
+    src = rnd(rows, cols, dtype=dtype, seed=4)
+    order = HF.segment_order(idx, n_dst, skip)
+    key = torch.where((idx < 0) | (idx == skip), torch.full_like(idx, 1 << 30), idx).long()
+    want = torch.sort(key * rows + torch.arange(rows, device="cuda"), stable=True)[1].int()
+    assert torch.equal(order, want)
+    outs = []
+    for rep in range(3):
+        dst = torch.full((n_dst, cols), 0.5, device="cuda")
+        HF.k_scatter_add_sorted(src, idx, dst, skip)
+        outs.append(dst)
+    keep = (idx >= 0) & (idx != skip)
+    ref = torch.full((n_dst, cols), 0.5, device="cuda", dtype=torch.float64)
+    ref.index_add_(0, idx[keep].long(), src[keep].double())
+    torch.testing.assert_close(outs[0].double(), ref, rtol=1e-5, atol=1e-4 * (rows / max(n_dst, 1) + 8))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_csr_gather_and_elementwise(HF, Lb):

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("HERO_HIP_LIB") or os.path.join(_HERE, "libhero_hip.so
 
 F32, BF16 = 0, 1
 LAYOUT_K, LAYOUT_O = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DG, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
     "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",

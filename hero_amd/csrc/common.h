@@ -181,6 +181,15 @@ template <> __device__ __forceinline__ float gelu_grad<bf16_t>(float x) {
   return fmaf(x * 0.39894228040143267794f, g.q, g.cdf);
 }
 
+// gelu(x) and gelu'(x) from ONE evaluation of Phi / the Gaussian (HERO_ACT_GELU_DG)
+template <typename T> __device__ __forceinline__ void gelu_both(float x, float& y, float& dy);
+template <> __device__ __forceinline__ void gelu_both<float>(float x, float& y, float& dy) { y = gelu_erf(x); dy = gelu_erf_grad(x); }
+template <> __device__ __forceinline__ void gelu_both<bf16_t>(float x, float& y, float& dy) {
+  const GeluFast g(x);
+  y = x * g.cdf;
+  dy = fmaf(x * 0.39894228040143267794f, g.q, g.cdf);
+}
+
 // error plumbing (api.cpp)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

@@ -277,7 +277,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   DropCtx drop(e.dropout);
   const T* R = (GEN || (EK & EK_RES)) ? static_cast<const T*>(e.residual) : nullptr;
   T* X = static_cast<T*>(e.aux);
-  const int act = GEN ? e.act : ((EK & EK_GELU) ? HERO_ACT_GELU : ((EK & EK_GELU_BWD) ? HERO_ACT_GELU_BWD : HERO_ACT_NONE));
+  // the specialised instantiations serve two activation codes each (a uniform run-time choice inside the same epilogue):
+  // GELU / GELU_DG (what is saved: the pre-activation or the derivative), GELU_BWD / MUL_AUX (what is read back)
+  const int act = GEN ? e.act
+                      : ((EK & EK_GELU) ? (e.act == HERO_ACT_GELU_DG ? HERO_ACT_GELU_DG : HERO_ACT_GELU)
+                                        : ((EK & EK_GELU_BWD) ? (e.act == HERO_ACT_MUL_AUX ? HERO_ACT_MUL_AUX : HERO_ACT_GELU_BWD) : HERO_ACT_NONE));
   const bool use_bias = GEN ? (e.bias != nullptr) : ((EK & EK_BIAS) != 0);
   const bool use_drop = (GEN || (EK & EK_DROP)) && drop.on();
   const bool out_f32 = GEN && e.out_f32;
@@ -292,7 +296,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   const int gnc = min(gn, g.N - 4);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (use_bias) bias4 = *reinterpret_cast<const float4*>(e.bias + gnc);
-  const bool ld_aux = act == HERO_ACT_GELU_BWD || act == HERO_ACT_RELU_BWD;
+  const bool ld_aux = act == HERO_ACT_GELU_BWD || act == HERO_ACT_RELU_BWD || act == HERO_ACT_MUL_AUX;
   const bool ld_c = out_f32 && e.beta != 0.f;
   constexpr int RSTEP = NT / C4;                 // rows covered per iteration
   // The specialised bf16 epilogues fetch the residual / saved pre-activation of the WHOLE pass up
@@ -362,6 +366,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         if (act == HERO_ACT_GELU) {
           if (ok[u]) V4<T>::st(X + off[u], v);
           v.x = gelu_fwd<T>(v.x); v.y = gelu_fwd<T>(v.y); v.z = gelu_fwd<T>(v.z); v.w = gelu_fwd<T>(v.w);
+        } else if (act == HERO_ACT_GELU_DG) {
+          float4 dg;
+          gelu_both<T>(v.x, v.x, dg.x); gelu_both<T>(v.y, v.y, dg.y); gelu_both<T>(v.z, v.z, dg.z); gelu_both<T>(v.w, v.w, dg.w);
+          if (ok[u]) V4<T>::st(X + off[u], dg);
+        } else if (act == HERO_ACT_MUL_AUX) {
+          v.x *= uu[u].x; v.y *= uu[u].y; v.z *= uu[u].z; v.w *= uu[u].w;
         } else if (GEN && act == HERO_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           if (X && ok[u]) V4<T>::st(X + off[u], v);
@@ -919,10 +929,10 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
     const bool b = e.bias != nullptr, r = e.residual != nullptr, d = e.dropout.threshold16 != 0;
     if (e.act == HERO_ACT_NONE && b && !r && !d) return launch_glds_ek<T, CF, EK_BIAS>(g, s);
     if (e.act == HERO_ACT_NONE && b && r) return launch_glds_ek<T, CF, EK_BIAS | EK_RES | EK_DROP>(g, s);
-    if (e.act == HERO_ACT_GELU && b && !r && !d) return launch_glds_ek<T, CF, EK_BIAS | EK_GELU>(g, s);
+    if ((e.act == HERO_ACT_GELU || e.act == HERO_ACT_GELU_DG) && b && !r && !d) return launch_glds_ek<T, CF, EK_BIAS | EK_GELU>(g, s);
     if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch_glds_ek<T, CF, 0>(g, s);
     if (e.act == HERO_ACT_NONE && !b && r && !d) return launch_glds_ek<T, CF, EK_RES>(g, s);
-    if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch_glds_ek<T, CF, EK_GELU_BWD>(g, s);
+    if ((e.act == HERO_ACT_GELU_BWD || e.act == HERO_ACT_MUL_AUX) && !b && !r && !d) return launch_glds_ek<T, CF, EK_GELU_BWD>(g, s);
   }
   return launch_glds_ek<T, CF, EK_GENERIC>(g, s);
 }
@@ -1002,7 +1012,8 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
                "hero_gemm: B contiguous dim must be a multiple of %d (N=%d K=%d layout=%d)", vec, N, K, b_layout);
   HERO_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "hero_gemm: operands must be 16-byte aligned");
   HERO_REQUIRE(!epi->residual || (((uintptr_t)epi->residual) & 7) == 0, "hero_gemm: residual misaligned");
-  HERO_REQUIRE(!(epi->act == HERO_ACT_GELU || epi->act == HERO_ACT_GELU_BWD || epi->act == HERO_ACT_RELU_BWD) || epi->aux,
+  HERO_REQUIRE(!(epi->act == HERO_ACT_GELU || epi->act == HERO_ACT_GELU_BWD || epi->act == HERO_ACT_RELU_BWD || epi->act == HERO_ACT_GELU_DG ||
+                 epi->act == HERO_ACT_MUL_AUX) || epi->aux,
                "hero_gemm: activation %d needs aux", epi->act);
   HERO_REQUIRE(!epi->colsum || (epi->split_k <= 1 && !epi->out_f32), "hero_gemm: epilogue.colsum excludes split_k / out_f32");
   GemmArgs g;

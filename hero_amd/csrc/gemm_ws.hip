@@ -926,13 +926,13 @@ template <int TM, int TN>
 static int launch_kk(const WsArgs& g, hipStream_t s) {
   const HeroGemmEpilogue& e = g.epi;
   const bool b = e.bias != nullptr, r = e.residual != nullptr, d = e.dropout.threshold16 != 0;
-  if (e.colsum != nullptr && e.act != HERO_ACT_GELU_BWD) return -1;     // column sums exist in the gelu' epilogue only: 4-wave path
+  if (e.colsum != nullptr && e.act != HERO_ACT_GELU_BWD && e.act != HERO_ACT_MUL_AUX) return -1;     // column sums exist in the gelu' epilogue only: 4-wave path
   if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, TM == 3 ? 8 : 10, s);
   if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, TM == 3 ? 8 : 10, s);
-  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, TM == 3 ? 8 : 10, s);
+  if ((e.act == HERO_ACT_GELU || e.act == HERO_ACT_GELU_DG) && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, TM == 3 ? 8 : 10, s);
   if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, TM == 3 ? 8 : 10, s);
   if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, TM == 3 ? 8 : 10, s);
-  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, TM == 3 ? 8 : 10, s);
+  if ((e.act == HERO_ACT_GELU_BWD || e.act == HERO_ACT_MUL_AUX) && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, TM == 3 ? 8 : 10, s);
   return -1;
 }
 
@@ -1262,10 +1262,14 @@ extern "C" int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int
   g.items = reinterpret_cast<const WsbItem*>(plan_dev + PLAN_HDR);
   g.rounds = (plan_words - PLAN_HDR) / (8 * num_cus());
   g.K = K; g.nprob = n; g.pad_ = 0;
-  static int* flags = nullptr;             // resolved once, outside any stream capture of later calls
-  if (!flags) HERO_REQUIRE(hipGetSymbolAddress(reinterpret_cast<void**>(&flags), HIP_SYMBOL(hero::ws::g_wsb_flags)) == hipSuccess,
-                           "hero_wgrad_batch: flag storage");
-  g.flags = flags;
+  // resolved once PER DEVICE (a __device__ symbol has one address per device), outside any stream capture of later calls
+  static int* flags_of[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  HERO_REQUIRE(dev >= 0 && dev < 64, "hero_wgrad_batch: device %d", dev);
+  if (!flags_of[dev]) HERO_REQUIRE(hipGetSymbolAddress(reinterpret_cast<void**>(&flags_of[dev]), HIP_SYMBOL(hero::ws::g_wsb_flags)) == hipSuccess,
+                                   "hero_wgrad_batch: flag storage");
+  g.flags = flags_of[dev];
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);

@@ -253,6 +253,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
     bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
   }
   const bool do_csum = (EK & EK_GELU_BWD) && e.colsum != nullptr;
+  const bool save_dg = (EK & EK_GELU) && e.act == HERO_ACT_GELU_DG, mul_aux = (EK & EK_GELU_BWD) && e.act == HERO_ACT_MUL_AUX;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
   // A pass stages 64 rows.  With three passes over a 192-row tile the two 32-row blocks of a pass are taken from the
@@ -316,10 +317,17 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
         for (int k = 0; k < 8; ++k) v[k] += bias[k];
         if (EK & EK_GELU) {
           uint4 u;
-          u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
-          auxv[(EK & EK_GELU) ? it : 0] = u;
+          if (save_dg) {                                // uniform (HERO_ACT_GELU_DG): the derivative is saved, not the pre-activation
+            float dg[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
+            for (int k = 0; k < 8; ++k) gelu_both<bf16_t>(v[k], v[k], dg[k]);
+            u.x = f2bf_pk(dg[0], dg[1]); u.y = f2bf_pk(dg[2], dg[3]); u.z = f2bf_pk(dg[4], dg[5]); u.w = f2bf_pk(dg[6], dg[7]);
+          } else {
+            u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
+          }
+          auxv[(EK & EK_GELU) ? it : 0] = u;
         }
         float pv[8];                                  // residual / saved pre-activation as fp32
         if (EK & (EK_RES | EK_GELU_BWD)) {
@@ -331,8 +339,13 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
           }
         }
         if (EK & EK_GELU_BWD) {
+          if (mul_aux) {                                // uniform (HERO_ACT_MUL_AUX): aux already holds gelu'
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] *= gelu_grad<bf16_t>(pv[k]);
+            for (int k = 0; k < 8; ++k) v[k] *= pv[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= gelu_grad<bf16_t>(pv[k]);
+          }
         }
         if (use_drop) {
           const int gm = ic.m0 + tile_row(p, row);

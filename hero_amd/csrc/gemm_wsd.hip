@@ -124,9 +124,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
           uint4 u = {0u, 0u, 0u, 0u};
           if (EK & EK_GELU) {
-            u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
+            if (e.act == HERO_ACT_GELU_DG) {               // uniform: save gelu'(v) instead of v
+              float dg[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
+              for (int k = 0; k < 8; ++k) gelu_both<bf16_t>(v[k], v[k], dg[k]);
+              u.x = f2bf_pk(dg[0], dg[1]); u.y = f2bf_pk(dg[2], dg[3]); u.z = f2bf_pk(dg[4], dg[5]); u.w = f2bf_pk(dg[6], dg[7]);
+            } else {
+              u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] = gelu_fwd<bf16_t>(v[k]);
+            }
           }
           float pv[8];
           if (HAS_PRE) {
@@ -138,8 +145,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
           }
           if (EK & EK_GELU_BWD) {
+            if (e.act == HERO_ACT_MUL_AUX) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= gelu_grad<bf16_t>(pv[k]);
+              for (int k = 0; k < 8; ++k) v[k] *= pv[k];
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] *= gelu_grad<bf16_t>(pv[k]);
+            }
           }
           if (use_drop) {
             const uint64_t grp = ((uint64_t)gm * (uint64_t)g.N + (uint64_t)gn) >> 2;
@@ -380,10 +392,10 @@ int launch_kk_deferred(const WsArgs& g, hipStream_t s) {
   if (g.K / 64 < (G::RPP * G::C8 / 256) * G::PASSES / 2) return -1;
   if (e.act == HERO_ACT_NONE && b && !r && !d) return launch_d<TM, TN, EK_BIAS>(g, slot, s);
   if (e.act == HERO_ACT_NONE && b && r) return launch_d<TM, TN, EK_BIAS | EK_RES | EK_DROP>(g, slot, s);
-  if (e.act == HERO_ACT_GELU && b && !r && !d) return launch_d<TM, TN, EK_BIAS | EK_GELU>(g, slot, s);
+  if ((e.act == HERO_ACT_GELU || e.act == HERO_ACT_GELU_DG) && b && !r && !d) return launch_d<TM, TN, EK_BIAS | EK_GELU>(g, slot, s);
   if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch_d<TM, TN, 0>(g, slot, s);
   if (e.act == HERO_ACT_NONE && !b && r && !d) return launch_d<TM, TN, EK_RES>(g, slot, s);
-  if (e.act == HERO_ACT_GELU_BWD && !b && !r && !d) return launch_d<TM, TN, EK_GELU_BWD>(g, slot, s);
+  if ((e.act == HERO_ACT_GELU_BWD || e.act == HERO_ACT_MUL_AUX) && !b && !r && !d) return launch_d<TM, TN, EK_GELU_BWD>(g, slot, s);
   return -1;
 }
 template int launch_kk_deferred<3, 3>(const WsArgs&, hipStream_t);

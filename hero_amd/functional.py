@@ -1313,8 +1313,11 @@ class FfnBlockFn(torch.autograd.Function):
         shp = a.shape
         a2 = _as2d(a)
         W1, W2 = packed((w1,), a2.dtype), packed((w2,), a2.dtype)
+        # `u` receives gelu'(a W1^T + b1), not the pre-activation (round 4, HERO_ACT_GELU_DG): nothing else reads it, both
+        # come out of one evaluation of Phi, and the backward epilogue becomes a multiply (HERO_ACT_MUL_AUX: ~7 us of exp /
+        # rcp / polynomial per 12000 x 3072 launch, tools/lab/gelu_ab.py)
         u = torch.empty((a2.shape[0], W1.shape[0]), dtype=a2.dtype, device=a2.device)
-        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU, aux=u)
+        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU_DG, aux=u)
         y2 = k_linear(hg, W2, b2.detach(), residual=a2, drop=drop_hid)
         out, mean, rstd, _ = k_ln_fwd(y2, g2.detach(), bt2.detach(), eps, y2.dtype, y2.shape[0], y2.shape[1])
         ctx.drop, ctx.shp = drop_hid, shp
@@ -1343,7 +1346,7 @@ class FfnBlockFn(torch.autograd.Function):
         # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
         # would be a 74 MB column-sum launch per layer.
         fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0])
-        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD, aux=u,       # * gelu'(u), fused
+        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_MUL_AUX, aux=u,        # * gelu'(pre-activation) = the saved tensor, fused
                        colsum=SINK.dst(b1) if fuse_b1 else None)
         acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)
         if fuse_b1:

@@ -166,6 +166,7 @@ class StaticBatchFeeder:
         if self.dc.f_v_feats is None:
             self.static["f_v_feats"] = host_batch["f_v_feats"].to(self.device)
         self.static.update(self.dc.batch_entries())
+        self.static["_static_buffers"] = True        # TrainStep: padded formulation only (the pack plan is host-derived)
         # TWO staging sets, used alternately: the copy stream fills one while the commit of the previous batch reads the
         # other, so the only ordering the copy stream needs - "the commit that read this set two batches ago is done" -
         # is checked on the HOST (Event.synchronize, already satisfied in steady state).  A stream-side

@@ -38,6 +38,23 @@ def qkv_groups(model):
     return groups
 
 
+class _padded_only:
+    """Switch the packed (ragged) formulation of BertEncoder off for the duration (no-op when `on` is false)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            from .model.layers import BertEncoder
+            self.prev, BertEncoder.allow_packing = BertEncoder.allow_packing, False
+
+    def __exit__(self, *exc):
+        if self.on:
+            from .model.layers import BertEncoder
+            BertEncoder.allow_packing = self.prev
+
+
 class TrainStep:
     def __init__(self, model, opts=None, task="tvr", bucket_bytes=64 << 20, use_graph=False, static_usage=False,
                  grad_compress="bf16", uniform_shapes=False, graph_collectives=None):
@@ -62,7 +79,7 @@ class TrainStep:
         self.micro = 0
         self.global_step = 0
         D.broadcast_tensors([p.data for p in model.parameters()], 0)     # train_vcmr.py:152
-        D.UNIFORM_SHAPES[0] = bool(uniform_shapes)
+        self.uniform_shapes = bool(uniform_shapes)      # applied around each forward (_fwd_bwd): not a process-wide setting
         if graph_collectives is None:
             graph_collectives = os.environ.get("HERO_DP_GRAPH", "0") not in ("", "0")
         self.use_graph = use_graph and (not D.collectives_active() or (graph_collectives and uniform_shapes))
@@ -78,7 +95,7 @@ class TrainStep:
     def enable_graph(self, collectives=False):
         """Switch an eager trainer to hipGraph replay (the next micro_step / prepare captures).  collectives: allow
         it in a data-parallel run - needs uniform_shapes (see __init__)."""
-        if D.collectives_active() and not (collectives and D.UNIFORM_SHAPES[0]):
+        if D.collectives_active() and not (collectives and self.uniform_shapes):
             raise RuntimeError("graph replay of a data-parallel step needs collectives=True and uniform_shapes=True")
         if self.micro % self.opts.gradient_accumulation_steps != 0:
             raise RuntimeError("switch to graph replay on an accumulation boundary")
@@ -87,7 +104,12 @@ class TrainStep:
     # ---- pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch, task=None):
         HF.advance_seed()
-        with HF.weights_frozen():                   # inside the step only the optimiser changes weights
+        # A batch whose BUFFERS are rewritten between steps (hero_amd.loader.StaticBatchFeeder, DeviceCollate batches fed to
+        # a captured step) must run the padded formulation: the packed one derives a row plan - and the packed row COUNT -
+        # from the masks on the host, a captured graph would replay the plan of the capture batch on every later batch
+        # (ADVICE r3).  Enforced here, for eager steps on such batches too, so both modes compute the same thing.
+        with _padded_only(batch.get("_static_buffers") if hasattr(batch, "get") else False), HF.weights_frozen(), \
+                D.uniform_shapes(self.uniform_shapes):
             out = self.model(batch, task=task or self.task, compute_loss=True)
             # 'tvr' / 'vsm': (loss_st_ed, loss_neg_ctx, loss_neg_q) summed (train_vcmr.py:216-226, pretrain.py:283-290);
             # 'mlm' / 'mfm-nce' / 'fom': one loss tensor

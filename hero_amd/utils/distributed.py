@@ -369,6 +369,21 @@ def _host_group():
 UNIFORM_SHAPES = [False]
 
 
+class uniform_shapes:
+    """`with uniform_shapes(True):` every rank feeds batches of the same padded shape inside - gather_negatives skips its
+    host-side size exchange.  Scoped (a TrainStep sets it around its own forwards): a second TrainStep in the process
+    cannot flip the first one's behaviour."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, UNIFORM_SHAPES[0] = UNIFORM_SHAPES[0], self.on
+
+    def __exit__(self, *exc):
+        UNIFORM_SHAPES[0] = self.prev
+
+
 def gather_negatives(query, context, context_mask, return_own=False):
     """All-gather (queries, L2-normalised contexts, masks) across ranks, padding contexts to the
     global max clip length.  ONE small integer all-gather carries every size needed.

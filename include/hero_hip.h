@@ -57,7 +57,11 @@ enum { HERO_ACT_NONE = 0,
        HERO_ACT_GELU = 1,     /* fwd: aux <- acc+bias (pre-activation), out <- gelu_erf(.)     */
        HERO_ACT_RELU = 2,     /* fwd: out <- relu(acc+bias); aux <- that value (pre-residual) */
        HERO_ACT_GELU_BWD = 3, /* bwd: out <- acc * gelu_erf'(aux)                              */
-       HERO_ACT_RELU_BWD = 4  /* bwd: out <- acc * (aux > 0)                                   */ };
+       HERO_ACT_RELU_BWD = 4, /* bwd: out <- acc * (aux > 0)                                   */
+       HERO_ACT_GELU_DG = 5,  /* fwd: out <- gelu_erf(acc+bias); aux <- gelu_erf'(acc+bias): the   */
+                              /*      derivative is saved instead of the pre-activation (BertIntermediate, */
+                              /*      model/layers.py:236-239: nothing else reads it), so that ...  */
+       HERO_ACT_MUL_AUX = 6   /* bwd: out <- acc * aux   ... the backward epilogue is one multiply  */ };
 
 typedef struct HeroGemmEpilogue {
   const float* bias;    /* [N] fp32 or NULL                                                  */

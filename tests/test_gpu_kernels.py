@@ -392,6 +392,34 @@ def test_deferred_weight_gradients_are_flushed_with_the_backward_pass(HF, Lb):
         torch.testing.assert_close(w.grad, r.grad, rtol=5e-2, atol=5e-2 * float(r.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(12000, 3072, 768), (1920, 3072, 768), (300, 136, 64)])
+def test_gemm_gelu_saved_derivative(HF, Lb, dtype, M, N, K):
+    """HERO_ACT_GELU_DG / HERO_ACT_MUL_AUX (round 4): BertIntermediate's GEMM saves gelu'(pre-activation) instead of the
+    pre-activation, the gradient GEMM multiplies by the saved tensor - on the wave-specialised, the 4-wave and the
+    generic epilogues, against fp32 torch (erf form, model/layers.py:16-25)."""
+    if dtype == torch.float32 and M > 2000:
+        pytest.skip("large shape only in the product dtype")
+    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
+    aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    y = HF.k_linear(x, w, b, act=Lb.ACT_GELU_DG, aux=aux)
+    pre = x.float() @ w.float().t() + b
+    pre.requires_grad_(True)
+    ref = torch.nn.functional.gelu(pre)
+    (dref,) = torch.autograd.grad(ref.sum(), pre)
+    sc = math.sqrt(K) * 0.05
+    close(y, ref.detach(), dtype, scale=sc)
+    close(aux, dref, dtype, scale=1.0)
+    # the same tensors through the old pair give the same forward output bit for bit
+    aux2 = torch.empty_like(aux)
+    y2 = HF.k_linear(x, w, b, act=Lb.ACT_GELU, aux=aux2)
+    assert torch.equal(y, y2)
+    dy, wt = rnd(M, K, dtype=dtype, seed=5), rnd(N, K, dtype=dtype, seed=6, scale=0.05)     # [M, K] @ [N, K]^T -> [M, N]
+    du = HF.k_dgrad_t(dy, wt, act=Lb.ACT_MUL_AUX, aux=aux)
+    want = (dy.float() @ wt.float().t()) * aux.float()
+    close(du, want, dtype, scale=sc)
+
+
 @pytest.mark.parametrize("M,N,K", [(1440, 50272, 768), (360, 8200, 768), (1440, 16384, 136)])
 def test_dgrad_long_reduction_small_output(HF, Lb, M, N, K):
     """functional._dgrad_long_reduction: dx = dy @ Wt^T with a vocabulary-long reduction (configs[3]: the MLM decoder's

@@ -79,6 +79,10 @@ def test_static_feeder_feeds_a_stream_of_batches(use_graph):
             ts.micro_step(d0)
         want = [float(ts.micro_step(to_dev(host[i], "cuda"))) for i in order]
         HF.set_grad_sink(None)
+        # with packing at its default (ON) a captured step would bake the capture batch's pack plan in and
+        # replay it on the later, differently ragged batches.  The feeder marks its static batch and TrainStep runs the
+        # padded formulation for it, eagerly and captured - nothing to remember for the caller.
+        BertEncoder.allow_packing = True
 
         ts = TrainStep(fresh(), opts=opts, use_graph=use_graph)
         feeder = StaticBatchFeeder(pin_batch(host[0]), "cuda")

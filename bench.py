@@ -107,9 +107,10 @@ def build_pretraining_model(device, cfg_path):
     return model
 
 
-def cpu_baseline(model, cfg, sample_videos=16, reps=5, threads=16):
+def cpu_baseline(model, cfg, sample_videos=32, reps=3, threads=16):
     """The CPU oracle (kind 'port': verified == reference in tests/test_oracle_golden.py) timed on
-    this box's host cores on a bounded sample of the same workload.  16 threads: measured best on the GPU box
+    this box's host cores on the SAME workload: the full 32-video D2 batch (rounds 1-3 timed a 16-video
+    slice), 1 warm-up + 3 timed steps of ~4.5 s.  16 threads: measured best on the GPU box
     (tools/cpu_threads_probe.py on 256 logical CPUs: 8 -> 4.6, 16 -> 6.6, 32 -> 5.9, 64 -> 2.9, 128 (torch's default)
     -> 1.3 videos/s; the oracle's small per-subtitle ops do not scale past one CCD)."""
     from hero_amd.synth import make_batch
@@ -136,8 +137,8 @@ def cpu_baseline(model, cfg, sample_videos=16, reps=5, threads=16):
     med = times[len(times) // 2]
     return {"value": sample_videos / med, "unit": "videos/s", "cores": threads,
             "kind": "port",
-            "sample": "%d-video slice of the D2 batch, fwd+loss+bwd fp32, dropout 0.1, 1 warm-up + %d timed, "
-                      "median %.2f s" % (sample_videos, reps, med)}
+            "sample": "%s D2 batch (%d videos), fwd+loss+bwd fp32, dropout 0.1, 1 warm-up + %d timed, "
+                      "median %.2f s" % ("the full" if sample_videos == 32 else "a slice of the", sample_videos, reps, med)}
 
 
 def _timed(trainer, batch, task, steps, warmup, world):

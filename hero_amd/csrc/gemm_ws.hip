@@ -1136,7 +1136,8 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
   }
   const int T = (int)tiles.size();
   const int full = T / nwg, rem = T % nwg;
-  if (full == 0 && T < nwg / 4) return 0;          // a handful of tiles: the stream-K group kernel cuts finer
+  // (round 3 left groups of fewer than nwg / 4 tiles to the stream-K group kernel, whose fp32 atomics land in any order;
+  // the sliced tail keeps them ordered, and such groups are a few microseconds either way)
   // Tail (tiles % nwg != 0): the remaining tiles are dealt to the XCDs (per_xcd each) and every XCD balances its p tiles
   // over its c = nwg / 8 workgroups.  Each workgroup gets a quota of q = ceil(p ksteps / c) k-steps:
   //   * every tile is cut into S = floor(c / p) "big" slices of q steps on S x p workgroups (round 0 of the tail);

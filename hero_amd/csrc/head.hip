@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void query_pool_bwd_kernel(HeroQueryPool a) {
       V4<T>::st(dq + (size_t)l * a.D + d, make_float4(fmaf(p, g.x, s * w.x), fmaf(p, g.y, s * w.y), fmaf(p, g.z, s * w.z), fmaf(p, g.w, s * w.w)));
       dw.x = fmaf(s, v.x, dw.x); dw.y = fmaf(s, v.y, dw.y); dw.z = fmaf(s, v.z, dw.z); dw.w = fmaf(s, v.w, dw.w);
     }
-    if (a.dw) { atomicAdd(a.dw + d, dw.x); atomicAdd(a.dw + d + 1, dw.y); atomicAdd(a.dw + d + 2, dw.z); atomicAdd(a.dw + d + 3, dw.w); }
+    // dw: [B, D] partial sums, one row per query (round 4; the caller folds them in a fixed order - round 3 added the B
+    // shares to one [D] vector with fp32 atomics)
+    if (a.dw) *reinterpret_cast<float4*>(a.dw + (size_t)b * a.D + d) = dw;
   }
 }
 
@@ -254,15 +256,25 @@ __global__ __launch_bounds__(256) void rank_loss_kernel(HeroRankLoss a) {
     rank_term(a, pos, neg, l, g);
     loss += w * l;
     dpos -= w * g;
-    if (qside) atomicAdd(ds + (size_t)c * a.nv + own, w * g * scale);   // `per` positives share a column
-    else ds[(size_t)m * a.nv + c] = w * g * scale;
+    if (!qside) {
+      ds[(size_t)m * a.nv + c] = w * g * scale;
+    } else if (m % per == 0) {
+      // the `per` positive queries of a video share its column: the first of them writes the cell, adding the `per`
+      // terms in a fixed order (round 3: every positive's workgroup added its own term with an fp32 atomic)
+      float tot = 0.f;
+      for (int j = 0; j < per; ++j) {
+        float lj, gj;
+        rank_term(a, a.s[(size_t)(own * per + j) * a.nv + own], neg, lj, gj);
+        tot += w * gj * scale;
+      }
+      ds[(size_t)c * a.nv + own] = tot;
+    }
   }
   loss = block_sum(loss, red);
   dpos = block_sum(dpos, red);
   if (threadIdx.x == 0) {
     (qside ? a.loss_q_rows : a.loss_ctx_rows)[m] = loss / (float)nneg;
-    if (qside) atomicAdd(ds + (size_t)m * a.nv + own, dpos * scale);
-    else ds[(size_t)m * a.nv + own] = dpos * scale;
+    ds[(size_t)m * a.nv + own] = dpos * scale;       // the positive's own cell: one writer on either side
   }
 }
 
@@ -368,18 +380,38 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
     }
     dsim[j] = v;
   }
-  // conv weight gradients: dw[k] = sum_l dlogit[l] * sim[l + k - half]
-  for (int k = 0; k < a.K; ++k) {
-    float s0 = 0.f, s1 = 0.f;
-    for (int l = threadIdx.x; l < a.L; l += 256) {
-      const int j = l + k - half;
-      if (j >= 0 && j < a.L) { s0 += dl[l] * sim[j]; s1 += dl[a.L + l] * sim[j]; }
+  // conv weight gradients: dw[k] = sum_b sum_l dlogit_b[l] * sim_b[l + k - half].  Round 4: workgroup 0 sums ALL pairs in a
+  // fixed order (thread t owns positions t, t + 256, ... of every pair; the dlogits are two multiplies from saved
+  // tensors) instead of every workgroup adding its share with fp32 atomics - the result no longer depends on the order
+  // 32 atomics land in.  K <= MAXK (launcher).
+  if (b == 0 && (a.dw_st || a.dw_ed)) {
+    float s0[MAXK + 1], s1[MAXK + 1];
+#pragma unroll
+    for (int k = 0; k < MAXK + 1; ++k) s0[k] = s1[k] = 0.f;
+    for (int bb = 0; bb < a.B; ++bb) {
+      const long long t0 = a.targets[2 * bb], t1 = a.targets[2 * bb + 1];
+      for (int l = threadIdx.x; l < a.L; l += 256) {
+        const float mk = a.mask[(size_t)bb * a.L + l];
+        const float d0 = t0 != -1 ? g * (a.p_st[(size_t)bb * a.L + l] - (l == t0 ? 1.f : 0.f)) / c0 * mk : 0.f;
+        const float d1 = t1 != -1 ? g * (a.p_ed[(size_t)bb * a.L + l] - (l == t1 ? 1.f : 0.f)) / c1 * mk : 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXK + 1; ++k) {
+          const int j = l + k - half;
+          if (k < a.K && j >= 0 && j < a.L) {
+            const float sv = a.sim[(size_t)bb * a.L + j];
+            s0[k] = fmaf(d0, sv, s0[k]);
+            s1[k] = fmaf(d1, sv, s1[k]);
+          }
+        }
+      }
     }
-    s0 = block_sum(s0, red);
-    s1 = block_sum(s1, red);
-    if (threadIdx.x == 0) {
-      if (a.dw_st) atomicAdd(a.dw_st + k, s0);
-      if (a.dw_ed) atomicAdd(a.dw_ed + k, s1);
+#pragma unroll
+    for (int k = 0; k < MAXK + 1; ++k) {
+      const float r0 = block_sum(s0[k], red), r1 = block_sum(s1[k], red);
+      if (threadIdx.x == 0 && k < a.K) {
+        if (a.dw_st) a.dw_st[k] += r0;
+        if (a.dw_ed) a.dw_ed[k] += r1;
+      }
     }
   }
   __syncthreads();

@@ -625,7 +625,10 @@ static int run_colred(const void* x, const void* dy, const float* mean, const fl
   hipLaunchKernelGGL((colred_kernel<TX, T>), dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, a);
   int rc = check_launch("colred");
   if (rc || a.atomic) return rc;
-  const int zs = (beta == 1.f && nchunks >= 128) ? 8 : 1;
+  // (round 3 cut long folds into 8 z-slices that added their shares with fp32 atomics: order-dependent sums; one slice
+  // folds 256 partial rows in a few microseconds, and the result is the same every run)
+  const int zs = 1;
+  (void)beta;
   hipLaunchKernelGGL(colred_final_kernel, dim3((cols + 15) / 16, 1, zs), dim3(256), 0, s, a.pg, a.pb, x ? og : nullptr, ob, cols,
                      nchunks, beta);
   return check_launch("colred_final");
@@ -722,7 +725,7 @@ extern "C" int hero_layernorm_bwd(const HeroLnBwd* a, hero_stream_t stream) {
 #undef CALLF
     int rc = check_launch("hero_layernorm_bwd(fused)");
     if (rc || a->defer_fold) return rc;
-    const int zs = (a->grad_beta == 1.f && nblk >= 128) ? 8 : 1;
+    const int zs = 1;               // fixed-order fold (see run_colred)
     hipLaunchKernelGGL(colred_final3_kernel, dim3((a->cols + 63) / 64, 3, zs), dim3(256), 0, s, partial, a->dgamma, a->dbeta,
                        a->dbias_in, a->cols, nblk, a->grad_beta);
     return check_launch("hero_layernorm_bwd(final3)");

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(SORT_NT) void segment_sort_kernel(const int32_t* __
 // workspace (slot 0: the block's first run continues from the previous block, slot 1: its last run continues into the
 // next one), and the second kernel lets the wave of the run's FIRST block add the partials up in block order.
 constexpr int SEG_B = 32;
+constexpr int UNR = 8;        // source rows in flight per wave
 __device__ __forceinline__ int seg_key(const int32_t* idx, const int32_t* order, int i, int rows, int skip) {
   if (i < 0 || i >= rows) return -2;
   const int v = idx[order[i]];
@@ -171,12 +172,12 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(const TS* __restric
 #pragma unroll
     for (int k = 0; k < NCH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     int seg_start = 0;
-    for (int p0 = 0; p0 < n; p0 += 4) {
-      // four rows in flight (the loads of a row only depend on the shuffled row number)
-      float4 v[4][NCH];
-      int keys[4];
+    for (int p0 = 0; p0 < n; p0 += UNR) {
+      // UNR rows in flight (the loads of a row only depend on the shuffled row number)
+      float4 v[UNR][NCH];
+      int keys[UNR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         const int p = min(p0 + u, n - 1);
         keys[u] = __shfl(my_key, p, 64);
         const int r = __shfl(my_row, p, 64);
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(const TS* __restric
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UNR; ++u) {
         const int p = p0 + u;
         if (p < n) {
           const int key = keys[u];

@@ -387,6 +387,7 @@ def _split_for(n_out, n_in, rows, bk):
 # count changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
 # pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
 # The queue keeps dY / X alive until then (~1 GB for HERO-base at 12000 rows).
+GELU_SAVE_U = [os.environ.get("HERO_GELU_SAVE_U", "") != ""]      # HERO_GELU_SAVE_U=1: FFN1 saves the pre-activation as in rounds 1-3 (A/B)
 DETERMINISTIC_SCATTER = [os.environ.get("HERO_ATOMIC_SCATTER", "") == ""]    # HERO_ATOMIC_SCATTER=1: the fp32-atomic embedding scatter of rounds 1-3 (A/B)
 _WQ = []
 _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
@@ -1317,7 +1318,7 @@ class FfnBlockFn(torch.autograd.Function):
         # come out of one evaluation of Phi, and the backward epilogue becomes a multiply (HERO_ACT_MUL_AUX: ~7 us of exp /
         # rcp / polynomial per 12000 x 3072 launch, tools/lab/gelu_ab.py)
         u = torch.empty((a2.shape[0], W1.shape[0]), dtype=a2.dtype, device=a2.device)
-        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU_DG, aux=u)
+        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU if GELU_SAVE_U[0] else L.ACT_GELU_DG, aux=u)
         y2 = k_linear(hg, W2, b2.detach(), residual=a2, drop=drop_hid)
         out, mean, rstd, _ = k_ln_fwd(y2, g2.detach(), bt2.detach(), eps, y2.dtype, y2.shape[0], y2.shape[1])
         ctx.drop, ctx.shp = drop_hid, shp
@@ -1346,7 +1347,7 @@ class FfnBlockFn(torch.autograd.Function):
         # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
         # would be a 74 MB column-sum launch per layer.
         fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0])
-        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_MUL_AUX, aux=u,        # * gelu'(pre-activation) = the saved tensor, fused
+        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD if GELU_SAVE_U[0] else L.ACT_MUL_AUX, aux=u,    # * gelu'(pre-activation) = the saved tensor, fused
                        colsum=SINK.dst(b1) if fuse_b1 else None)
         acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)
         if fuse_b1:

@@ -46,15 +46,16 @@ class QueryPoolFn(torch.autograd.Function):
         B, Lq, D = q.shape
         dq = torch.empty_like(q)
         to_sink = HF._is_param(w)
-        dw = HF.SINK.dst(w).view(-1) if to_sink else torch.zeros(D, dtype=torch.float32, device=q.device)
+        part = torch.empty((B, D), dtype=torch.float32, device=q.device)     # per-query shares of dw, folded in a fixed order
         a = L.QueryPool()
         a.q, a.mask, a.w, a.att = L.ptr(q), L.ptr(mask), L.ptr(w.detach().contiguous()), L.ptr(att)
-        a.dpooled, a.dq, a.dw = L.ptr(_f32c(dpooled)), L.ptr(dq), L.ptr(dw)
+        a.dpooled, a.dq, a.dw = L.ptr(_f32c(dpooled)), L.ptr(dq), L.ptr(part)
         a.B, a.L, a.D, a.dtype = B, Lq, D, L.dt(q)
         L.check(L.lib().hero_query_pool_bwd(C.byref(a), L.stream()))
         if to_sink:
-            HF.SINK.done(w)
-        return dq, None, (None if to_sink else dw.view_as(w))
+            HF.k_colsum(part, out=HF.SINK.dst(w).view(-1), beta=1.0, on_done=lambda: HF.SINK.done(w))
+            return dq, None, None
+        return dq, None, HF.k_colsum(part).view_as(w)
 
 
 class RowNormFn(torch.autograd.Function):

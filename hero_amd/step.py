@@ -104,6 +104,10 @@ class TrainStep:
     # ---- pieces ------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch, task=None):
         HF.advance_seed()
+        # dropout sites restart with every step: a site is then the SAME number in the eager step and in its captured
+        # replay (a capture freezes the site numbers it saw; counting on across steps made the two modes draw different
+        # masks), the per-step seed word keeps the steps apart - graph replay and eager runs follow one trajectory
+        HF.RNG.site = 0
         # A batch whose BUFFERS are rewritten between steps (hero_amd.loader.StaticBatchFeeder, DeviceCollate batches fed to
         # a captured step) must run the padded formulation: the packed one derives a row plan - and the packed row COUNT -
         # from the masks on the host, a captured graph would replay the plan of the capture batch on every later batch

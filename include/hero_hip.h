@@ -380,7 +380,8 @@ typedef struct HeroQueryPool {
   float* att;             /* fwd out / bwd in [B, L]                                            */
   const float* dpooled;   /* bwd in [B, D]                                                      */
   void* dq;               /* bwd out [B, L, D] dtype                                            */
-  float* dw;              /* bwd out [D], ACCUMULATED (+=)                                      */
+  float* dw;              /* bwd out [B, D]: per-query shares of dw, OVERWRITTEN; the caller sums the  */
+                          /* rows (hero_colsum): a fixed-order sum instead of B-way fp32 atomics       */
   int B, L, D, dtype;
 } HeroQueryPool;
 int hero_query_pool_fwd(const HeroQueryPool* a, hero_stream_t stream);

@@ -342,7 +342,7 @@ def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
 
 def test_wgrad_batch_ragged_shapes_and_small_groups(HF, Lb):
     """Output shapes that are not multiples of the 192 x 192 tile (4352-wide projections, a 1000 x 776 weight), a
-    column-sliced dY, and the plan refusing groups smaller than one round of the chip (-> hero_wgrad_group)."""
+    column-sliced dY, and groups smaller than one round of the chip (sliced tails only)."""
     import numpy as np
     rows = 1920
     shapes = [(768, 4352), (1000, 776), (768, 4352), (2304, 768), (768, 3072), (3072, 768)]
@@ -358,8 +358,18 @@ def test_wgrad_batch_ragged_shapes_and_small_groups(HF, Lb):
         torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
     assert float((outs[3][768:] - 0.25).abs().max()) == 0.0          # rows of dW outside the problem are untouched
     buf = np.zeros(8 + 8 * 256 * 16, dtype=np.int32)
-    small = (Lb.WgradProblem * 1)(probs[3])                          # 16 tiles: left to the stream-K group kernel
-    assert Lb.lib().hero_wgrad_batch_plan(small, 1, rows, buf.ctypes.data, buf.size) == 0
+    # a handful of tiles (16): round 3 left such groups to the stream-K group kernel (fp32 atomics in any order); round 4
+    # runs them as a sliced tail too, ordered atomics - bit-reproducible like the large groups
+    small = (Lb.WgradProblem * 1)(probs[3])
+    assert Lb.lib().hero_wgrad_batch_plan(small, 1, rows, buf.ctypes.data, buf.size) > 8
+    again = []
+    for rep in range(3):
+        outs[3].fill_(0.25)
+        plan = _run_batch(Lb, small, 1, rows)
+        assert plan[6] == 16
+        again.append(outs[3][:768].clone())
+    torch.testing.assert_close(again[0], wide[:, 768:1536].float().t() @ xs[3].float() + 0.25, rtol=1e-4, atol=1e-3 * math.sqrt(rows))
+    assert torch.equal(again[0], again[1]) and torch.equal(again[0], again[2])
     # a group smaller than one round of the chip (two 4352-wide projections: 184 tiles) runs as a sliced tail only
     two = (Lb.WgradProblem * 2)(probs[0], probs[2])
     for o in (outs[0], outs[2]):

@@ -387,6 +387,7 @@ def _split_for(n_out, n_in, rows, bk):
 # count changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
 # pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
 # The queue keeps dY / X alive until then (~1 GB for HERO-base at 12000 rows).
+B1_EPILOGUE = [os.environ.get("HERO_B1_EPILOGUE", "") != ""]      # HERO_B1_EPILOGUE=1: FFN1 bias gradient from the gelu' epilogue's fp32 atomics (rounds 1-3; A/B)
 GELU_SAVE_U = [os.environ.get("HERO_GELU_SAVE_U", "") != ""]      # HERO_GELU_SAVE_U=1: FFN1 saves the pre-activation as in rounds 1-3 (A/B)
 DETERMINISTIC_SCATTER = [os.environ.get("HERO_ATOMIC_SCATTER", "") == ""]    # HERO_ATOMIC_SCATTER=1: the fp32-atomic embedding scatter of rounds 1-3 (A/B)
 _WQ = []
@@ -1346,7 +1347,7 @@ class FfnBlockFn(torch.autograd.Function):
         # two places that made a step's result depend on the order atomics landed in.  Only where the weight gradients go
         # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
         # would be a 74 MB column-sum launch per layer.
-        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0])
+        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0] or B1_EPILOGUE[0])
         du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD if GELU_SAVE_U[0] else L.ACT_MUL_AUX, aux=u,    # * gelu'(pre-activation) = the saved tensor, fused
                        colsum=SINK.dst(b1) if fuse_b1 else None)
         acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)

@@ -140,8 +140,13 @@ def test_hero_base_bf16_full_d2_batch_vs_oracle():
     report = hip_report(model, b, batch, ref_frames, ref_losses, ref_grads, R, GRAD_NAMES)
     assert report["repr.max"] < BF16_MAX_TOL and report["repr.l2"] < BF16_L2_TOL, report
     assert all(v < 2e-2 for k, v in report.items() if k.startswith("loss.")), report
-    # bf16 activations + bf16 activation gradients through 9 layers: measured 0.7 - 4 % (relative L2)
-    assert all(v < 0.06 for k, v in report.items() if k.startswith("grad.")), report
+    # bf16 activations + bf16 activation gradients through 9 layers (relative L2, printed above).  Measured in round 4:
+    # 0.7 - 1.4 % for eight of the nine probes, 3.8 % for frame_transform.net.1.weight (its input is the bf16-rounded
+    # LayerNorm of 4352 raw features, its output gradient the sum of the whole temporal stack's): gate 4 % (was 6 %),
+    # 2 % for the others
+    grads = {k: v for k, v in report.items() if k.startswith("grad.")}
+    assert all(v < 0.04 for v in grads.values()), report
+    assert all(v < 0.02 for k, v in grads.items() if "frame_transform" not in k), report
 
 
 def test_bf16_error_growth_per_layer():
@@ -300,8 +305,10 @@ def test_graph_replay_long_run_with_midrun_sync_converges_like_eager():
     rel = ((l_g - l_e).abs() / l_e.abs().clamp(min=5e-2))
     print("graph vs eager, relative difference of the losses: first 16 %.3g, first 40 %.3g, first 100 %.3g" %
           (float(rel[:16].max()), float(rel[:40].max()), float(rel[:100].max())))
-    torch.testing.assert_close(l_g[:16], l_e[:16], rtol=5e-2, atol=5e-3)       # same trajectory early on (fp32 atomics
-    torch.testing.assert_close(l_g[:40], l_e[:40], rtol=0.25, atol=5e-2)       # reorder sums: chaotic divergence later)
+    # Round 4: the step has no order-dependent sums left and the dropout sites restart per step, so the replayed run follows
+    # the eager one (measured: identical losses over all 320 micro-steps; rounds 1-3 needed 5 % / 25 % over the first 16 / 40
+    # steps because fp32 atomics reordered sums and the two modes drew different masks)
+    torch.testing.assert_close(l_g, l_e, rtol=2e-2, atol=2e-3)
     tail_e, tail_g = float(l_e[-20:].mean()), float(l_g[-20:].mean())
     assert float(l_e[0]) > 1.0
     assert tail_e < 0.3, tail_e                        # the eager run has over-fitted its one batch ...

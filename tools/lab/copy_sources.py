@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Who makes large device-to-device copies in a micro-step (__amd_rocclr_copyBuffer in the kernel trace): wraps
-Tensor.copy_ / clone / contiguous / torch.cat and the autograd engine's accumulations are visible as the rest.
-`ragged` = the D2r batch."""
-import collections, json, os, sys, traceback
+"""Who issues the device-to-device copies (__amd_rocclr_copyBuffer in the kernel trace) of a micro-step: chrome trace of
+two steps; every hipMemcpy* runtime call is matched to the CPU ops that enclose it.  `ragged` = the D2r batch."""
+import collections, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 import hero_amd
 from hero_amd.step import TrainStep
 from hero_amd.synth import make_batch
+from torch.profiler import profile, ProfilerActivity
 
 hero_amd.set_compute_dtype(torch.bfloat16)
 dev = torch.device("cuda", 0)
@@ -20,38 +20,29 @@ batch = make_batch("D2", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev,
 for _ in range(4):
     tr.micro_step(batch)
 torch.cuda.synchronize()
-log = collections.Counter()
-size = collections.Counter()
-
-
-def frame():
-    for f in reversed(traceback.extract_stack()[:-2]):
-        if "hero_amd/" in f.filename and "copy_sources" not in f.filename:
-            return "%s:%d %s" % (f.filename.split("hero_amd/")[-1], f.lineno, f.name)
-    return "?"
-
-
-def wrap(name, fn, big):
-    def w(*a, **k):
-        r = fn(*a, **k)
-        t = a[0] if torch.is_tensor(a[0]) else (r if torch.is_tensor(r) else None)
-        n = big(a, r)
-        if n >= (1 << 20):
-            key = (name, frame())
-            log[key] += 1
-            size[key] += n
-        return r
-    return w
-
-
-torch.Tensor.copy_ = wrap("copy_", torch.Tensor.copy_, lambda a, r: a[0].numel() * a[0].element_size() if a[0].is_cuda else 0)
-torch.Tensor.clone = wrap("clone", torch.Tensor.clone, lambda a, r: r.numel() * r.element_size() if r.is_cuda else 0)
-_c = torch.Tensor.contiguous
-torch.Tensor.contiguous = wrap("contiguous", _c, lambda a, r: (r.numel() * r.element_size()) if (r.is_cuda and r.data_ptr() != a[0].data_ptr()) else 0)
 N = 2
-for _ in range(N):
-    tr.micro_step(batch)
-torch.cuda.synchronize()
-print("%6s %9s  op / first hero_amd frame" % ("calls", "MB/step"))
-for key, n in sorted(size.items(), key=lambda kv: -kv[1])[:25]:
-    print("%6.1f %9.1f  %s | %s" % (log[key] / N, n / N / 2 ** 20, *key))
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
+    for _ in range(N):
+        tr.micro_step(batch)
+    torch.cuda.synchronize()
+prof.export_chrome_trace("/tmp/hero_trace.json")
+tr_ = json.load(open("/tmp/hero_trace.json"))["traceEvents"]
+cpu_ops = [e for e in tr_ if e.get("cat") in ("cpu_op", "user_annotation", "python_function") and "dur" in e]
+rt = [e for e in tr_ if e.get("cat") in ("cuda_runtime", "hip_runtime", "cuda_driver") and "emcpy" in e.get("name", "")]
+dev_copies = {e["args"].get("correlation"): e for e in tr_ if e.get("cat") in ("gpu_memcpy", "gpu_memset") and "args" in e}
+count, dur, size = collections.Counter(), collections.Counter(), collections.Counter()
+for r in rt:
+    ts, tid = r["ts"], r.get("tid")
+    encl = [o for o in cpu_ops if o.get("tid") == tid and o["ts"] <= ts <= o["ts"] + o["dur"]]
+    encl.sort(key=lambda o: o["dur"])
+    names = [o["name"].replace("autograd::engine::evaluate_function: ", "bwd:") for o in encl[:5]]
+    shapes = str(encl[0].get("args", {}).get("Input Dims", ""))[:60] if encl else ""
+    d = dev_copies.get(r.get("args", {}).get("correlation"))
+    key = (r["name"], " < ".join(names), shapes)
+    count[key] += 1
+    if d is not None:
+        dur[key] += d.get("dur", 0)
+        size[key] += d.get("args", {}).get("bytes", 0) or 0
+print("%6s %8s %8s  runtime call | enclosing ops | input dims" % ("calls", "us/step", "MB/step"))
+for key, n in sorted(count.items(), key=lambda kv: -dur[kv[0]])[:30]:
+    print("%6.1f %8.1f %8.1f  %s | %s | %s" % (n / N, dur[key] / N, size[key] / N / 2 ** 20, *key))

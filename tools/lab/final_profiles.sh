@@ -1,8 +1,8 @@
-# one gpurun call: the committed evidence of the round (profiles/r03_*): kernel stats + PMC passes of the bench step,
+# one gpurun call: the committed evidence of the round (profiles/r0N_*): kernel stats + PMC passes of the bench step,
 # kernel stats of the secondary workloads, the bench lines.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out; mkdir -p $OUT
-TAG=${1:-r03}
+TAG=${1:-r04}
 bash tools/profile_run.sh $TAG > $OUT/${TAG}_run.log 2>&1
 export TMPDIR=/tmp
 R=$PWD
@@ -15,6 +15,8 @@ done
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_D4 -o s -- python $R/bench.py --workload D4 --videos 256 --steps 2 --warmup 2 > /dev/null 2> $R/$OUT/${TAG}_stats_D4.log)
 python tools/profile_summary.py stats $OUT/${TAG}_stats_D4 6 $OUT/${TAG}_kernel_stats_D4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload D4 --videos 256 --steps 2 --warmup 2 (MI355X; 256 videos x 256 frames per step)"
 find $OUT/${TAG}_stats_D4 -name "*kernel_trace.csv" -delete
+# the line reads its counters from profiles/ (stamped with the kernel-source hash): the passes of THIS call
+cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_mfma.json profiles/
 (timeout 600 python bench.py --steps 20 --warmup 4) > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 (timeout 600 python bench.py --steps 20 --warmup 4 --feed 4 --no-cpu-baseline | tail -1) > $OUT/${TAG}_bench_feed.json 2>> $OUT/${TAG}_bench.err
 for w in D2r D3 D4; do

@@ -77,7 +77,7 @@ class LnBwd(C.Structure):
 
 class Colsum(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
-                ("dtype", C.c_int), ("beta", C.c_float)]
+                ("dtype", C.c_int), ("beta", C.c_float), ("row_cols", C.c_int), ("dst_rows", C.c_void_p)]
 
 
 class Attn(C.Structure):

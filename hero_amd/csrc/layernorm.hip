@@ -763,6 +763,7 @@ extern "C" int hero_layernorm_bwd_blocks(int rows) {
 }
 
 // ---- many column sums, two launches --------------------------------------------------------------------------------
+// (passed by value: the whole struct must stay under the 4 KB kernel-argument limit - 64 x 48 + 772 bytes)
 struct ColsumMulti {
   HeroColsum p[HERO_COLSUM_MULTI_MAX];
   int blk0[HERO_COLSUM_MULTI_MAX + 1];    // first workgroup of problem i (stage 1: col-blocks x chunks; stage 2: 16-column groups)
@@ -847,9 +848,18 @@ __global__ __launch_bounds__(256) void colsum_multi_fold_kernel(ColsumMulti a, c
   __syncthreads();
   if (threadIdx.x < 16 && c < P.cols) {
     s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-    P.dst[c] = (P.beta != 0.f ? P.beta * P.dst[c] : 0.f) + s;
+    if (P.dst_rows) {
+      // indexed destination rows (periodic position ids): distinct rows receive exactly one value per launch, so the
+      // atomic is order-free; only a clamped id that repeats inside one period (positions beyond 511) shares a row
+      const int j = c / P.row_cols, r = P.dst_rows[j];
+      if (r >= 0) atomicAdd(P.dst + (size_t)r * P.row_cols + (c - j * P.row_cols), s);
+    } else {
+      P.dst[c] = (P.beta != 0.f ? P.beta * P.dst[c] : 0.f) + s;
+    }
   }
 }
+
+static_assert(sizeof(ColsumMulti) <= 4000, "kernel argument size");
 
 static int colsum_multi_plan(const HeroColsum* p, int n, ColsumMulti* a, int* fold_blocks, size_t* ws_floats) {
   size_t off = 0;
@@ -884,6 +894,8 @@ extern "C" int hero_colsum_multi(const HeroColsum* p, int n, void* workspace, he
     HERO_REQUIRE(p[i].src && p[i].dst && p[i].rows > 0 && p[i].cols > 0 && p[i].cols % 4 == 0 && p[i].ld % 4 == 0 &&
                      (p[i].dtype == HERO_BF16 || p[i].dtype == HERO_F32) && ((uintptr_t)p[i].src & 7) == 0,
                  "hero_colsum_multi: bad problem %d", i);
+    HERO_REQUIRE(!p[i].dst_rows || (p[i].beta == 1.f && p[i].row_cols > 0 && p[i].cols % p[i].row_cols == 0),
+                 "hero_colsum_multi: problem %d: dst_rows needs beta = 1 and cols a multiple of row_cols", i);
   }
   ColsumMulti a, f;
   size_t fl = 0;

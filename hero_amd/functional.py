@@ -400,6 +400,33 @@ _WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) o
 _WPLANS_PINNED = set()   # keys whose plan tensor a captured graph references by address
 
 
+def _wgrad_queue_full(device):
+    """Byte budget of the queue (it keeps dY / X alive).  Past the soft cap (HERO_WGRAD_QUEUE_MB, 4 GB) the queue is
+    flushed as soon as its tiles fill whole rounds of the chip - or a tail the plan can slice evenly; past the hard cap
+    (15 % of the device memory) in any case.  Config 5 is what this is for: one BertLayer there is 5-20 GB of dY and 192
+    tiles = 3/4 of a round; round 3 flushed layer by layer (75 % fill: 0.30 of peak instead of 0.43), round 4 lets two
+    layers pair up (384 tiles: one full round + 128 tiles in two even slices)."""
+    if _WQ_BYTES[0] <= WGRAD_QUEUE_BYTES[0]:
+        return False
+    hard = _WQ_HARD.get(device.index)
+    if hard is None:
+        env = os.environ.get("HERO_WGRAD_QUEUE_HARD_MB")
+        hard = (int(env) << 20) if env else max(2 * WGRAD_QUEUE_BYTES[0], int(0.15 * torch.cuda.get_device_properties(device).total_memory))
+        _WQ_HARD[device.index] = hard
+    if _WQ_BYTES[0] > hard:
+        return True
+    tiles = sum(-(-e[4] // 192) * -(-e[1].shape[1] // 192) for e in _WQ)
+    full, rem = divmod(tiles, 256)
+    if rem == 0:
+        return True
+    p = -(-rem // 8)
+    slices = max(1, min(32 // p, 8))
+    return tiles / 256.0 >= 0.9 * (full + 1.0 / slices)
+
+
+_WQ_HARD = {}
+
+
 def _wgrad_limit():
     return 4 if (WGRAD_BATCH[0] <= 4 or SINK.wants_overlap()) else min(WGRAD_BATCH[0], 32)
 
@@ -453,13 +480,14 @@ def _colsum_defer_ok():
     return GROUP_WGRADS[0] and not SINK.wants_overlap() and torch._C._current_graph_task_id() != -1
 
 
-def _colsum_queue(keep, src_ptr, dst, rows, cols, ld, dtype, on_done=None):
+def _colsum_queue(keep, src_ptr, dst, rows, cols, ld, dtype, on_done=None, dst_rows=None, row_cols=0):
+    """dst_rows (int32 [cols / row_cols]) + row_cols: the column sums are added to dst's ROWS dst_rows[j] (hero_hip.h)."""
     task = torch._C._current_graph_task_id()
     if _CQ and _CQ_TASK[0] != task:
         del _CQ[:]                      # left behind by a backward pass that raised
     _CQ_TASK[0] = task
     _ensure_flush_callback(task)
-    _CQ.append((keep, L.Colsum(src_ptr, L.ptr(dst), rows, cols, ld, dtype, 1.0), dst, on_done))
+    _CQ.append(((keep, dst_rows), L.Colsum(src_ptr, L.ptr(dst), rows, cols, ld, dtype, 1.0, row_cols, L.ptr(dst_rows)), dst, on_done))
     if len(_CQ) >= 64:
         colsum_flush()
 
@@ -555,7 +583,7 @@ def k_wgrad(dy2, x2, out=None, beta=0.0, col0=0, ncols=None, on_done=None, dbias
         _ensure_flush_callback(task)
         _WQ.append((dy2, x2, out, col0, N, on_done, dbias, dbias_done))
         _WQ_BYTES[0] += dy2.numel() * dy2.element_size()
-        if len(_WQ) >= _wgrad_limit() or _WQ_BYTES[0] > WGRAD_QUEUE_BYTES[0]:
+        if len(_WQ) >= _wgrad_limit() or _wgrad_queue_full(dy2.device):
             wgrad_flush()
         return out
     if dbias is not None:
@@ -1026,8 +1054,16 @@ class EmbedLnFn(torch.autograd.Function):
                     grads_t.append(None)
                     continue
                 elif per and dx.shape[0] % per == 0 and dx.shape[0] // per >= 8:
-                    # periodic index (position ids broadcast over the sequences): fold the repeats with a
-                    # column sum over [S, period*D], then scatter `period` rows - not S-way contended atomics
+                    # periodic index (position ids broadcast over the sequences): fold the repeats with a column sum
+                    # over [S, period*D] and add the `period` rows to the table - not S-way contended atomics.  Round 4:
+                    # the fold joins the deferred multi-sum of the backward pass (its destination rows are indexed,
+                    # HeroColsum.dst_rows) instead of two reduction launches + a scatter of its own per table
+                    D_ = dx.shape[1]
+                    if (skip is None or skip < 0) and dx.is_contiguous() and (per * D_) % 4 == 0 and _colsum_defer_ok():
+                        _colsum_queue(dx, L.ptr(dx), SINK.dst(tab), dx.shape[0] // per, per * D_, per * D_, L.dt(dx),
+                                      on_done=lambda tab=tab: SINK.done(tab), dst_rows=idx[:per].contiguous(), row_cols=D_)
+                        grads_t.append(None)
+                        continue
                     folded = k_colsum(dx.view(dx.shape[0] // per, per * dx.shape[1]))
                     k_scatter_add(folded.view(per, dx.shape[1]), idx[:per], SINK.dst(tab), None, skip)
                 elif (DETERMINISTIC_SCATTER[0] and idx.dtype == torch.int32 and idx.is_contiguous() and dx.shape[1] % 4 == 0

@@ -193,6 +193,11 @@ typedef struct HeroColsum {
   float* dst;        /* [cols]                                                                         */
   int rows, cols, ld, dtype;   /* cols, ld multiples of 4                                              */
   float beta;
+  int row_cols;      /* with dst_rows: width of a destination row (cols = n_rows * row_cols)           */
+  const int32_t* dst_rows;     /* optional (hero_colsum_multi only; beta must be 1): the sum of columns  */
+                     /* [j * row_cols, (j + 1) * row_cols) is ADDED to dst + dst_rows[j] * row_cols - the fold   */
+                     /* of a periodic position-id gradient ([S, L * D] view of [S * L, D]) goes straight into  */
+                     /* the embedding table's rows (model/embed.py:28-58, 146-161); rows < 0 are dropped      */
 } HeroColsum;
 size_t hero_colsum_multi_workspace_bytes(const HeroColsum* p, int n);
 int hero_colsum_multi(const HeroColsum* p, int n, void* workspace, hero_stream_t stream);

@@ -22,7 +22,7 @@ EXPORTS = [
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
-    "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd",
+    "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd", "hero_st_ed_bwd_workspace_bytes",
     "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
     "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats", "hero_derive_multi",
 ]
@@ -149,7 +149,8 @@ class StEd(C.Structure):
                 ("w_ed", C.c_void_p), ("targets", C.c_void_p), ("loss_rows", C.c_void_p),
                 ("p_st", C.c_void_p), ("p_ed", C.c_void_p), ("sim", C.c_void_p), ("g", C.c_void_p),
                 ("dq2", C.c_void_p), ("dctx", C.c_void_p), ("dw_st", C.c_void_p), ("dw_ed", C.c_void_p),
-                ("B", C.c_int), ("L", C.c_int), ("D", C.c_int), ("K", C.c_int), ("dtype", C.c_int)]
+                ("B", C.c_int), ("L", C.c_int), ("D", C.c_int), ("K", C.c_int), ("dtype", C.c_int), ("pad_", C.c_int),
+                ("ws", C.c_void_p)]
 
 
 _lib = None
@@ -204,6 +205,8 @@ def lib():
         L.hero_scatter_add_sorted_workspace_bytes.restype = C.c_size_t
         L.hero_scatter_add_sorted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p]
+        L.hero_st_ed_bwd_workspace_bytes.argtypes = [C.c_int]
+        L.hero_st_ed_bwd_workspace_bytes.restype = C.c_size_t
         L.hero_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.hero_transpose_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]

@@ -380,37 +380,38 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
     }
     dsim[j] = v;
   }
-  // conv weight gradients: dw[k] = sum_b sum_l dlogit_b[l] * sim_b[l + k - half].  Round 4: workgroup 0 sums ALL pairs in a
-  // fixed order (thread t owns positions t, t + 256, ... of every pair; the dlogits are two multiplies from saved
-  // tensors) instead of every workgroup adding its share with fp32 atomics - the result no longer depends on the order
-  // 32 atomics land in.  K <= MAXK (launcher).
-  if (b == 0 && (a.dw_st || a.dw_ed)) {
-    float s0[MAXK + 1], s1[MAXK + 1];
-#pragma unroll
-    for (int k = 0; k < MAXK + 1; ++k) s0[k] = s1[k] = 0.f;
-    for (int bb = 0; bb < a.B; ++bb) {
-      const long long t0 = a.targets[2 * bb], t1 = a.targets[2 * bb + 1];
+  // conv weight gradients: dw[k] = sum_b sum_l dlogit_b[l] * sim_b[l + k - half].  Every workgroup leaves its pair's share
+  // in the workspace; the LAST one to arrive (a ticket) adds the B shares up in pair order: a fixed-order sum whoever
+  // comes last (round 3: every workgroup added its share with fp32 atomics, in whatever order they landed).
+  if (a.dw_st || a.dw_ed) {
+    float* part = a.ws + (size_t)b * (2 * (MAXK + 1));
+    for (int k = 0; k < a.K; ++k) {
+      float s0 = 0.f, s1 = 0.f;
       for (int l = threadIdx.x; l < a.L; l += 256) {
-        const float mk = a.mask[(size_t)bb * a.L + l];
-        const float d0 = t0 != -1 ? g * (a.p_st[(size_t)bb * a.L + l] - (l == t0 ? 1.f : 0.f)) / c0 * mk : 0.f;
-        const float d1 = t1 != -1 ? g * (a.p_ed[(size_t)bb * a.L + l] - (l == t1 ? 1.f : 0.f)) / c1 * mk : 0.f;
-#pragma unroll
-        for (int k = 0; k < MAXK + 1; ++k) {
-          const int j = l + k - half;
-          if (k < a.K && j >= 0 && j < a.L) {
-            const float sv = a.sim[(size_t)bb * a.L + j];
-            s0[k] = fmaf(d0, sv, s0[k]);
-            s1[k] = fmaf(d1, sv, s1[k]);
-          }
-        }
+        const int j = l + k - half;
+        if (j >= 0 && j < a.L) { s0 += dl[l] * sim[j]; s1 += dl[a.L + l] * sim[j]; }
       }
+      s0 = block_sum(s0, red);
+      s1 = block_sum(s1, red);
+      if (threadIdx.x == 0) { part[k] = s0; part[MAXK + 1 + k] = s1; }
     }
-#pragma unroll
-    for (int k = 0; k < MAXK + 1; ++k) {
-      const float r0 = block_sum(s0[k], red), r1 = block_sum(s1[k], red);
-      if (threadIdx.x == 0 && k < a.K) {
-        if (a.dw_st) a.dw_st[k] += r0;
-        if (a.dw_ed) a.dw_ed[k] += r1;
+    __shared__ int last_flag;
+    if (threadIdx.x == 0) {
+      __threadfence();                                                   // release: the shares above, agent scope
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (MI355X_MICROARCH.md: never let the flag overtake the write-back)
+      int* counter = reinterpret_cast<int*>(a.ws + (size_t)a.B * (2 * (MAXK + 1)));
+      last_flag = atomicAdd(counter, 1) == a.B - 1;
+      if (last_flag) { *counter = 0; __threadfence(); }                  // acquire (and leave the counter at zero)
+    }
+    __syncthreads();
+    if (last_flag && threadIdx.x < 2 * (MAXK + 1)) {
+      const int k = threadIdx.x % (MAXK + 1), which = threadIdx.x / (MAXK + 1);
+      if (k < a.K) {
+        float t = 0.f;
+        for (int bb = 0; bb < a.B; ++bb)
+          t += __hip_atomic_load(a.ws + (size_t)bb * (2 * (MAXK + 1)) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float* dw = which ? a.dw_ed : a.dw_st;
+        if (dw) dw[k] += t;
       }
     }
   }
@@ -513,11 +514,14 @@ extern "C" int hero_st_ed_fwd(const HeroStEd* a, hero_stream_t stream) {
   if (a->B <= 0) return HERO_OK;
   HERO_BY_DTYPE(a->dtype, st_ed_fwd_kernel, a->B, 3 * a->L * sizeof(float), static_cast<hipStream_t>(stream), *a, "hero_st_ed_fwd");
 }
+extern "C" size_t hero_st_ed_bwd_workspace_bytes(int B) { return ((size_t)(B > 0 ? B : 0) * 2 * (MAXK + 1) + 4) * sizeof(float); }
+
 extern "C" int hero_st_ed_bwd(const HeroStEd* a, hero_stream_t stream) {
   HERO_REQUIRE(a && a->q2 && a->ctx && a->mask && a->w_st && a->w_ed && a->targets && a->p_st && a->p_ed && a->sim && a->g && a->dq2 && a->dctx,
                "hero_st_ed_bwd: null pointer");
   HERO_REQUIRE(a->L > 0 && a->L <= 2048 && a->D % 4 == 0 && a->K >= 1 && a->K <= MAXK && (a->K & 1), "hero_st_ed_bwd: bad dims L=%d D=%d K=%d",
                a->L, a->D, a->K);
+  HERO_REQUIRE(a->ws || !(a->dw_st || a->dw_ed), "hero_st_ed_bwd: dw_st / dw_ed need the workspace (hero_st_ed_bwd_workspace_bytes)");
   if (a->B <= 0) return HERO_OK;
   HERO_BY_DTYPE(a->dtype, st_ed_bwd_kernel, a->B, 4 * a->L * sizeof(float), static_cast<hipStream_t>(stream), *a, "hero_st_ed_bwd");
 }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(SORT_NT) void segment_sort_kernel(const int32_t* __
 // workspace (slot 0: the block's first run continues from the previous block, slot 1: its last run continues into the
 // next one), and the second kernel lets the wave of the run's FIRST block add the partials up in block order.
 constexpr int SEG_B = 32;
-constexpr int UNR = 8;        // source rows in flight per wave
+constexpr int UNR = 4;        // source rows (and their table rows) in flight per wave
 __device__ __forceinline__ int seg_key(const int32_t* idx, const int32_t* order, int i, int rows, int skip) {
   if (i < 0 || i >= rows) return -2;
   const int v = idx[order[i]];
@@ -173,18 +173,22 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(const TS* __restric
     for (int k = 0; k < NCH; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     int seg_start = 0;
     for (int p0 = 0; p0 < n; p0 += UNR) {
-      // UNR rows in flight (the loads of a row only depend on the shuffled row number)
-      float4 v[UNR][NCH];
+      // UNR rows in flight, and with them the table rows they may be added to: the loads only depend on the shuffled row
+      // numbers / keys, so a group costs ONE memory round trip (read-add-write per run, one after the other, was a round
+      // trip per run: 64 us for the 9600 sub-tokens of the bench batch, most of them runs of one)
+      float4 v[UNR][NCH], old[UNR][NCH];
       int keys[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int p = min(p0 + u, n - 1);
         keys[u] = __shfl(my_key, p, 64);
         const int r = __shfl(my_row, p, 64);
+        const int kd = max(keys[u], 0);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
           const int c = min(c0 + k * 256 + lane * 4, cols - 4);
           v[u][k] = V4<TS>::ld(src + (size_t)r * cols + c);
+          old[u][k] = *reinterpret_cast<const float4*>(dst + (size_t)kd * cols + c);
         }
       }
 #pragma unroll
@@ -201,16 +205,15 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(const TS* __restric
             if (key >= 0) {
               const bool left_open = seg_start == 0 && prev_key == key;
               const bool right_open = p == n - 1 && next_key == key;
-              float* out = (!left_open && !right_open) ? dst + (size_t)key * cols
-                                                       : partial + ((size_t)blk * 2 + (left_open ? 0 : 1)) * cols;
+              const bool closed = !left_open && !right_open;
+              float* out = closed ? dst + (size_t)key * cols : partial + ((size_t)blk * 2 + (left_open ? 0 : 1)) * cols;
 #pragma unroll
               for (int k = 0; k < NCH; ++k) {
                 const int c = c0 + k * 256 + lane * 4;
                 if (c < cols) {
-                  float4* d = reinterpret_cast<float4*>(out + c);
                   float4 o = acc[k];
-                  if (!left_open && !right_open) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-                  *d = o;
+                  if (closed) { o.x += old[u][k].x; o.y += old[u][k].y; o.z += old[u][k].z; o.w += old[u][k].w; }   // old[u]: this run's table row
+                  *reinterpret_cast<float4*>(out + c) = o;
                 }
               }
             }

@@ -421,7 +421,9 @@ def _wgrad_queue_full(device):
         return True
     p = -(-rem // 8)
     slices = max(1, min(32 // p, 8))
-    return tiles / 256.0 >= 0.9 * (full + 1.0 / slices)
+    # a sliced tail runs ~1.4x slower per flop than whole tiles (several k-streams per XCD share less in its L2, every
+    # slice adds a tile of atomics: 0.30 vs 0.43 of peak, profiles/r03_kernel_stats_D4.csv vs r03_kernel_stats.csv)
+    return tiles / 256.0 >= 0.9 * (full + (1.4 if slices > 1 else 1.0) / slices)
 
 
 _WQ_HARD = {}

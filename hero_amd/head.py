@@ -145,6 +145,19 @@ class VideoRankLossFn(torch.autograd.Function):
         return dqn, dcn, None, None, None, None, None, None, None
 
 
+_STED_WS = {}
+
+
+def _sted_workspace(B, dev):
+    """Scratch of hero_st_ed_bwd (per-pair shares + arrival counter): zero once, the kernel leaves the counter at zero;
+    reuse is stream-ordered."""
+    key = (dev.index, B)
+    t = _STED_WS.get(key)
+    if t is None:
+        t = _STED_WS[key] = torch.zeros(L.lib().hero_st_ed_bwd_workspace_bytes(B) // 4, dtype=torch.float32, device=dev)
+    return t
+
+
 class StEdLossFn(torch.autograd.Function):
     """loss_st_ed of matched (query, video) pairs: similarity, the two 1-D convolutions, mask_logits
     and both cross-entropies (model/pretrain.py:96-110, 128-166) -> scalar."""
@@ -194,6 +207,7 @@ class StEdLossFn(torch.autograd.Function):
         a = StEdLossFn._args(q2, ctxf, mask, w_st, w_ed, tg, saved, K)
         a.g = L.ptr(_f32c(g).reshape(1))
         a.dq2, a.dctx, a.dw_st, a.dw_ed = L.ptr(dq2), L.ptr(dctx), L.ptr(dws), L.ptr(dwe)
+        a.ws = L.ptr(_sted_workspace(q2.shape[0], dev))
         L.check(L.lib().hero_st_ed_bwd(C.byref(a), L.stream()))
         if sink:
             HF.SINK.done(w_st)

@@ -475,7 +475,13 @@ typedef struct HeroStEd {
   float* dw_st;           /* bwd out [K], ACCUMULATED (+=)                                      */
   float* dw_ed;           /* bwd out [K], ACCUMULATED (+=)                                      */
   int B, L, D, K, dtype;
+  int pad_;
+  float* ws;              /* bwd scratch, hero_st_ed_bwd_workspace_bytes(B) bytes, ZERO before the first */
+                          /* use (the kernel leaves its arrival counter at zero): per-pair shares of     */
+                          /* dw_st / dw_ed, folded in pair order by the last workgroup to arrive - the   */
+                          /* same sum every run (round 3: B-way fp32 atomics)                            */
 } HeroStEd;
+size_t hero_st_ed_bwd_workspace_bytes(int B);
 int hero_st_ed_fwd(const HeroStEd* a, hero_stream_t stream);
 int hero_st_ed_bwd(const HeroStEd* a, hero_stream_t stream);
 

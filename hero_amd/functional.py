@@ -1273,6 +1273,43 @@ class ProjResLnFn(torch.autograd.Function):
         return (dh, dy.view(ctx.rshape)) + (None,) * 6
 
 
+ONE_ATTN_LAUNCH = [os.environ.get("HERO_ATTN_PER_GROUP", "") == ""]     # HERO_ATTN_PER_GROUP=1: one attention launch per sequence group (A/B)
+_SEQ_OFF = {}
+
+
+def _one_attention_launch(segs, masks, drops, x2):
+    """Several padded sequence groups stacked along the rows (HERO's subtitle rows, 480 x 24, and its query rows, 32 x 15)
+    as ONE variable-length attention launch: `seq_off` lists every sequence of every group (rows back to back, nothing is
+    moved), the additive masks are stacked into one [sum S, max L] tensor (HeroAttn.mask is indexed [s, max L] with a
+    seq_off too).  The query group's launch - 384 waves, ~5 us forward / ~7 us backward plus two kernel boundaries per layer -
+    disappears into the subtitle one.  bf16 matrix-core kernels with row statistics only (L <= 64)."""
+    if not (ONE_ATTN_LAUNCH[0] and len(segs) > 1 and all(len(sg) == 2 for sg in segs) and x2.dtype == torch.bfloat16 and x2.is_cuda):
+        return segs, masks, drops
+    lmax = max(sg[1] for sg in segs)
+    if ATTN_SAVE_PROBS or not L.lib().hero_attention_stats_ok(L.BF16, lmax) or any(m is not None and m.requires_grad for m in masks):
+        return segs, masks, drops
+    key = (tuple(segs), x2.device.index)
+    off = _SEQ_OFF.get(key)
+    if off is None:
+        o, r = [0], 0
+        for S_, L_ in segs:
+            for _ in range(S_):
+                r += L_
+                o.append(r)
+        off = _SEQ_OFF[key] = torch.tensor(o, dtype=torch.int32, device=x2.device)
+    if all(m is None for m in masks):
+        mcat = None
+    else:
+        def build():
+            parts = []
+            for (S_, L_), m in zip(segs, masks):
+                mm = m.reshape(S_, L_).float() if m is not None else torch.zeros((S_, L_), dtype=torch.float32, device=x2.device)
+                parts.append(torch.nn.functional.pad(mm, (0, lmax - L_)) if L_ < lmax else mm)
+            return torch.cat(parts, 0).contiguous()
+        mcat = memo("attn_mask_cat", tuple(m for m in masks if m is not None), build, (tuple(segs),))
+    return (("packed", sum(sg[0] for sg in segs), lmax, off),), (mcat,), (drops[0],)
+
+
 class AttnBlockFn(torch.autograd.Function):
     """BertAttention (model/layers.py:217-222) as ONE node: a = LN(drop(MHA(x) Wo^T + bo) + x).
 
@@ -1290,12 +1327,13 @@ class AttnBlockFn(torch.autograd.Function):
         Wo = packed((wo,), x2.dtype)
         qkv = k_linear(x2, Wqkv, bqkv)
         ctxt = torch.empty((x2.shape[0], D), dtype=x2.dtype, device=x2.device)
+        segs, masks, drops_attn = _one_attention_launch(segs, masks, drops_attn, x2)
         probs = []
         r0 = 0
         for seg, m, dr in zip(segs, masks, drops_attn):          # each group writes its row slice
             if len(seg) == 4:                                    # ("packed", S, Lmax, seq_off): all rows
                 _, S, Lq, off = seg
-                _, p = k_attn_fwd(qkv, None, S, Lq, H, drop=dr, out=ctxt, seq_off=off)
+                _, p = k_attn_fwd(qkv, m, S, Lq, H, drop=dr, out=ctxt, seq_off=off)
                 probs.append(p)
                 continue
             S, Lq = seg
@@ -1333,7 +1371,7 @@ class AttnBlockFn(torch.autograd.Function):
         for seg, p, dr, m in zip(segs, probs, drops_attn, ctx.masks):
             if len(seg) == 4:
                 _, S, Lq, off = seg
-                k_attn_bwd(qkv, p, dctx, S, Lq, H, drop=dr, out=dqkv, seq_off=off, ctx=ctxt)
+                k_attn_bwd(qkv, p, dctx, S, Lq, H, drop=dr, out=dqkv, seq_off=off, ctx=ctxt, mask_add=m)
                 continue
             S, Lq = seg
             k_attn_bwd(qkv[r0:r0 + S * Lq], p, dctx[r0:r0 + S * Lq], S, Lq, H, drop=dr,

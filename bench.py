@@ -437,6 +437,11 @@ def main():
             dt_mute, _ = timed_run()
         finally:
             trainer.arena.mute = False
+        from hero_amd.utils import distributed as D
+        D.broadcast_tensors([p.data for p in model.parameters()], 0)       # the muted steps let the replicas drift: re-align
+        HF_ = __import__("hero_amd.functional", fromlist=["x"])
+        HF_.notify_weights_updated()
+        HF_.refresh_weight_cache()
         mute_ms = dt_mute / args.steps * 1e3
         comm = {"backend": torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""),
                 "ranks_seen": int(ones.item()), "wire_dtype": trainer.arena.compress or "f32",

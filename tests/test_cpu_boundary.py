@@ -412,3 +412,28 @@ def test_move_to_device_recurses_like_the_reference():
     assert b["x"].device.type == "meta" and b["nested"][0].device.type == "meta" and b["nested"][1][0].device.type == "meta"
     assert b["nested"][1][1:] == (7, "s") and b["lens"] == [3, 4] and isinstance(b["nested"][1], tuple)
     assert isinstance(b["nt"], NT) and b["nt"].a.device.type == "meta" and b["nt"].b is None
+
+
+def test_wgrad_queue_flushes_at_whole_round_points(monkeypatch):
+    """functional._wgrad_queue_full (host logic): under the soft byte cap nothing is flushed; past it the queue waits for
+    a tile count that fills whole rounds (or an evenly sliceable tail, priced 1.4x); past the hard cap it flushes anyway."""
+    import types
+    from hero_amd import functional as HF
+    monkeypatch.setenv("HERO_WGRAD_QUEUE_HARD_MB", "100")
+    monkeypatch.setattr(HF, "_WQ_HARD", {})
+    monkeypatch.setattr(HF, "WGRAD_QUEUE_BYTES", [10 << 20])
+    dev = types.SimpleNamespace(index=0)
+    layer = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]          # 64 + 64 + 16 + 48 tiles of 192 x 192
+
+    def queue(shapes, nbytes):
+        q = [(None, types.SimpleNamespace(shape=(1, k)), None, 0, n, None, None, None) for n, k in shapes]
+        monkeypatch.setattr(HF, "_WQ", q)
+        monkeypatch.setattr(HF, "_WQ_BYTES", [nbytes])
+        return HF._wgrad_queue_full(dev)
+
+    assert not queue(layer, 5 << 20)                       # under the soft cap
+    assert not queue(layer, 20 << 20)                      # 192 tiles: 3/4 of a round - wait for more
+    assert queue(layer + layer[:1], 20 << 20)              # 256 tiles: one whole round
+    assert not queue(layer[:2], 20 << 20)                  # 128 tiles would be two even slices: 0.71 of a whole-tile round
+    assert queue(layer[:2], 101 << 20)                     # ... but past the hard cap everything goes
+    assert queue(layer * 6, 20 << 20)                      # 1152 tiles = 4.5 rounds (the TVR stack): 4 whole + 128 in two slices

@@ -404,8 +404,8 @@ def _wgrad_queue_full(device):
     """Byte budget of the queue (it keeps dY / X alive).  Past the soft cap (HERO_WGRAD_QUEUE_MB, 4 GB) the queue is
     flushed as soon as its tiles fill whole rounds of the chip - or a tail the plan can slice evenly; past the hard cap
     (15 % of the device memory) in any case.  Config 5 is what this is for: one BertLayer there is 5-20 GB of dY and 192
-    tiles = 3/4 of a round; round 3 flushed layer by layer (75 % fill: 0.30 of peak instead of 0.43), round 4 lets two
-    layers pair up (384 tiles: one full round + 128 tiles in two even slices)."""
+    tiles = 3/4 of a round; round 3 flushed wherever the byte cap fell (192 tiles at the 256-video profiling size), round 4
+    waits for the next whole round (256 tiles = a layer and the first weight of the next one)."""
     if _WQ_BYTES[0] <= WGRAD_QUEUE_BYTES[0]:
         return False
     hard = _WQ_HARD.get(device.index)

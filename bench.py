@@ -444,6 +444,7 @@ def main():
         HF_.refresh_weight_cache()
         mute_ms = dt_mute / args.steps * 1e3
         comm = {"backend": torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""),
+                "exchange": "hero_comm_* (C ABI, side stream)" if trainer.arena.backend == "abi" else "torch.distributed process group",
                 "ranks_seen": int(ones.item()), "wire_dtype": trainer.arena.compress or "f32",
                 "buckets": len(trainer.arena.buckets), "payload_mb_per_opt_step": round(trainer.arena.wire_bytes() / 2 ** 20, 1),
                 "allreduce_ms_per_opt_step": round(ar_ms, 3),

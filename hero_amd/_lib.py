@@ -25,6 +25,8 @@ EXPORTS = [
     "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd", "hero_st_ed_bwd_workspace_bytes",
     "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
     "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats", "hero_derive_multi",
+    "hero_comm_available", "hero_comm_unique_id", "hero_comm_init", "hero_comm_destroy", "hero_comm_rank", "hero_comm_world",
+    "hero_comm_allreduce_buckets", "hero_comm_broadcast", "hero_comm_allgather",
 ]
 
 
@@ -153,6 +155,10 @@ class StEd(C.Structure):
                 ("ws", C.c_void_p)]
 
 
+class CommBucket(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("count", C.c_size_t), ("dtype", C.c_int), ("pad_", C.c_int)]
+
+
 _lib = None
 
 
@@ -230,6 +236,14 @@ def lib():
         L.hero_collate_frame_map.argtypes = [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]
         L.hero_cross_entropy_fwd.argtypes = [C.POINTER(CrossEntropy), C.c_void_p]
         L.hero_cross_entropy_bwd.argtypes = [C.POINTER(CrossEntropy), C.c_void_p]
+        L.hero_comm_unique_id.argtypes = [C.c_void_p]
+        L.hero_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.hero_comm_destroy.argtypes = [C.c_void_p]
+        L.hero_comm_rank.argtypes = [C.c_void_p]
+        L.hero_comm_world.argtypes = [C.c_void_p]
+        L.hero_comm_allreduce_buckets.argtypes = [C.c_void_p, C.POINTER(CommBucket), C.c_int, C.c_void_p]
+        L.hero_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.hero_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 

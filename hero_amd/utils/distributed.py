@@ -31,6 +31,11 @@ def rank():
     return dist.get_rank() if _on() else 0
 
 
+def _abi_on(t):
+    """HERO_COMM=1: device collectives go through hero_comm_* of the C ABI (hero_amd/utils/comm.py)."""
+    return os.environ.get("HERO_COMM") == "1" and t.is_cuda
+
+
 def collectives_active():
     """True when gradient buckets really travel through torch.distributed: more than one rank, or an initialised
     1-rank group with HERO_DP_FORCE_COLLECTIVES=1 (how the RCCL path - init, comm-stream ordering, bf16 wire - is
@@ -56,6 +61,14 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
         off += k
 
 
+def _broadcast(t, root):
+    if _abi_on(t):
+        from . import comm
+        comm.communicator().broadcast(t, root)
+    else:
+        dist.broadcast(t, src=root)
+
+
 def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
     """Bucketed broadcast of parameters from `root_rank` (utils/distributed.py:103-151)."""
     if world_size() == 1:
@@ -66,7 +79,7 @@ def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
         if not bucket:
             return
         flat = torch.cat([t.reshape(-1) for t in bucket])
-        dist.broadcast(flat, src=root_rank)
+        _broadcast(flat, root_rank)
         off = 0
         for t in bucket:
             t.copy_(flat[off:off + t.numel()].view_as(t))
@@ -74,8 +87,8 @@ def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
 
     for t in tensors:
         sz = t.numel() * t.element_size()
-        if sz > buffer_size:
-            dist.broadcast(t, src=root_rank)
+        if sz > buffer_size and t.is_contiguous():
+            _broadcast(t, root_rank)
             continue
         if filled + sz > buffer_size:
             flush()
@@ -101,7 +114,7 @@ class GradArena(HF.GradSink):
     """
 
     def __init__(self, params, bucket_bytes=64 << 20, overlap=True, install=True, groups=(),
-                 static_usage=False, compress=None):
+                 static_usage=False, compress=None, backend=None):
         """groups: tuples of parameters whose gradients must be CONTIGUOUS in the arena, in the given
         order (e.g. an attention block's query/key/value weights: the backward then writes
         d[Wq;Wk;Wv] with one GEMM instead of three, see hero_amd.functional._qkv_bwd)."""
@@ -149,6 +162,15 @@ class GradArena(HF.GradSink):
         if compress not in (None, "bf16"):
             raise ValueError("GradArena: compress must be None or 'bf16'")
         self._wire = {}
+        # backend: "torch" = torch.distributed's process group (default); "abi" = hero_comm_* of the C ABI (RCCL enqueued
+        # on a side stream this process owns, hero_amd/utils/comm.py) - HERO_COMM=1 selects it for CUDA arenas
+        if backend is None:
+            backend = "abi" if os.environ.get("HERO_COMM") == "1" and dev.type == "cuda" else "torch"
+        if backend not in ("torch", "abi"):
+            raise ValueError("GradArena: backend must be 'torch' or 'abi'")
+        self.backend = backend
+        self._comm = None
+        self._abi_open = False
         # static_usage: the caller guarantees that every optimiser step touches the same parameters
         # (one task, fixed graph).  Buckets then wait only for the parameters that received a gradient
         # in the previous step, so a bucket that also holds never-used parameters (pooler, lm_head,
@@ -241,7 +263,24 @@ class GradArena(HF.GradSink):
             return
         self._launched[b] = True
         s, e, _ = self.buckets[b]
-        if self.compress == "bf16":
+        if self.backend == "abi":
+            # fork the communicator's stream off the current one (the bucket's gradients are final in stream order),
+            # all-reduce there while backward continues here; finish() joins
+            c = self._abi()
+            buf = self.flat[s:e]
+            if self.compress == "bf16":
+                buf = self._wire.get(b)
+                if buf is None:
+                    buf = self._wire[b] = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
+                # the cast stays on THIS stream: a bandwidth kernel running beside the persistent GEMMs of backward takes
+                # CUs from their one-workgroup-per-CU launch and the late workgroups become a second round (measured:
+                # 7.50 vs 7.17 ms per captured micro-step with the cast on the side stream)
+                buf.copy_(self.flat[s:e])
+            c.fork()
+            c.allreduce_buckets([buf], stream=c.stream)
+            self._abi_open = True
+            self._handles.append((None, b if self.compress == "bf16" else None))
+        elif self.compress == "bf16":
             w = self._wire.get(b)
             if w is None:
                 w = self._wire[b] = torch.empty(e - s, dtype=torch.bfloat16, device=self.flat.device)
@@ -249,6 +288,12 @@ class GradArena(HF.GradSink):
             self._handles.append((dist.all_reduce(w, op=dist.ReduceOp.SUM, async_op=True), b))
         else:
             self._handles.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True), None))
+
+    def _abi(self):
+        if self._comm is None:
+            from . import comm
+            self._comm = comm.communicator()
+        return self._comm
 
     def set_sync(self, flag):
         """Call at the start of every micro-step; False on gradient-accumulation micro-steps that do
@@ -265,8 +310,12 @@ class GradArena(HF.GradSink):
         if collectives_active() and self.sync and not self.mute:
             for b in range(len(self.buckets)):
                 self._launch(b)
+            if self._abi_open:
+                self._comm.join()
+                self._abi_open = False
             for h, b in self._handles:
-                h.wait()
+                if h is not None:
+                    h.wait()
                 if b is not None:                       # widen the summed wire buffer back into the arena
                     s, e, _ = self.buckets[b]
                     self.flat[s:e].copy_(self._wire[b])
@@ -301,6 +350,17 @@ class GradArena(HF.GradSink):
         dt = torch.bfloat16 if self.compress == "bf16" else torch.float32
         bufs = [torch.zeros(e - s, dtype=dt, device=self.flat.device) for s, e, _ in self.buckets]
         times = []
+        if self.backend == "abi":
+            c = self._abi()
+            for _ in range(reps + 1):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                c.allreduce_buckets(bufs)                 # one group on the current stream
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1))
+            return sorted(times[1:])[len(times[1:]) // 2]
         for _ in range(reps + 1):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -332,8 +392,12 @@ class _AllGatherRows(torch.autograd.Function):
         mx = max(dims)
         buf = tensor.new_zeros((mx,) + tuple(tensor.shape[1:]))
         buf[:tensor.shape[0]] = tensor
-        out = [torch.empty_like(buf) for _ in range(n)]
-        dist.all_gather(out, buf.contiguous())
+        if _abi_on(buf):
+            from . import comm
+            out = comm.communicator().allgather(buf.contiguous())        # enqueued on the current stream
+        else:
+            out = [torch.empty_like(buf) for _ in range(n)]
+            dist.all_gather(out, buf.contiguous())
         ctx.offset, ctx.dim = sum(dims[:r]), tensor.shape[0]
         return torch.cat([o[:d] for o, d in zip(out, dims)], dim=0)
 

@@ -547,6 +547,29 @@ typedef struct HeroDerive {
 } HeroDerive;
 int hero_derive_multi(const HeroDerive* d, int n, hero_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Gradient exchange over RCCL (round 4) - replaces Horovod's allreduce_ / broadcast_ */
+/* (utils/distributed.py:19-46, 103-151) and the negatives' allgather (model/pretrain.py:427-451).  */
+/* Every collective is ENQUEUED on the caller's stream (no stream, thread or synchronisation of its  */
+/* own: a captured step simply contains it).  librccl.so is dlopen-ed by the first call;             */
+/* hero_comm_available() = 0 where it is missing.  One communicator per process = per GPU.          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct HeroCommBucket {
+  void* buf;        /* device buffer, reduced in place                                          */
+  size_t count;     /* elements                                                                 */
+  int dtype;        /* HERO_F32 or HERO_BF16 (the wire format of hero_amd.utils.distributed.GradArena) */
+  int pad_;
+} HeroCommBucket;
+int hero_comm_available(void);
+int hero_comm_unique_id(void* id128);                          /* rank 0: 128 bytes to hand to every rank       */
+int hero_comm_init(const void* id128, int rank, int world, void** comm_out);   /* collective; current device  */
+int hero_comm_destroy(void* comm);
+int hero_comm_rank(void* comm);
+int hero_comm_world(void* comm);
+int hero_comm_allreduce_buckets(void* comm, const HeroCommBucket* buckets, int n, hero_stream_t stream);  /* SUM, <= 64 buckets, one group */
+int hero_comm_broadcast(void* comm, void* buf, size_t bytes, int root, hero_stream_t stream);
+int hero_comm_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hero_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,7 +97,7 @@ def main():
     assert all(torch.equal(both[0], b) for b in both), "replicas diverged after optimiser steps"
     assert all(l == l and abs(l) < 1e4 for l in losses)
     torch.cuda.synchronize()
-    json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses, "backend": dist.get_backend(),
+    json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses, "backend": dist.get_backend(), "exchange": trainer.arena.backend,
                "collectives": bool(__import__("hero_amd.utils.distributed", fromlist=["x"]).collectives_active())},
               open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
     dist.destroy_process_group()

@@ -437,3 +437,25 @@ def test_wgrad_queue_flushes_at_whole_round_points(monkeypatch):
     assert not queue(layer[:2], 20 << 20)                  # 128 tiles would be two even slices: 0.71 of a whole-tile round
     assert queue(layer[:2], 101 << 20)                     # ... but past the hard cap everything goes
     assert queue(layer * 6, 20 << 20)                      # 1152 tiles = 4.5 rounds (the TVR stack): 4 whole + 128 in two slices
+
+
+def test_hero_comm_boundary_without_a_gpu(built_lib):
+    """hero_comm_*: librccl is dlopen-ed lazily (libhero_hip.so does not link it), rank 0's unique id is 128 bytes, and
+    argument errors come back as codes with a message - no collective is attempted without a communicator."""
+    import ctypes as C
+    import subprocess
+    from hero_amd import _lib
+    L = _lib.lib()
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    assert L.hero_comm_available() in (0, 1)
+    assert L.hero_comm_rank(None) == -1 and L.hero_comm_world(None) == 0 and L.hero_comm_destroy(None) == 0
+    arr = (_lib.CommBucket * 1)()
+    assert L.hero_comm_allreduce_buckets(None, arr, 1, None) != 0 and b"hero_comm" in L.hero_last_error()
+    assert L.hero_comm_broadcast(None, None, 0, 0, None) != 0
+    assert L.hero_comm_allgather(None, None, None, 0, None) != 0
+    if L.hero_comm_available():
+        uid = (C.c_char * 128)()
+        assert L.hero_comm_unique_id(uid) == 0 and any(uid.raw)
+        h = C.c_void_p()
+        assert L.hero_comm_init(uid, 2, 2, C.byref(h)) != 0 and b"bad arguments" in L.hero_last_error()

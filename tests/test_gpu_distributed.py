@@ -117,3 +117,83 @@ def test_bench_wedged_capture_falls_back_to_the_eager_line():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "timed out" in out["config"]["launch"] and out["config"]["launch"].startswith("eager")
     assert out["value"] > 0 and out["comm"]["ranks_seen"] == 1 and out["comm"]["graph_ms_per_step"] is None
+
+
+def test_hero_comm_abi_collectives_one_rank_eager_and_captured():
+    """hero_comm_* of the C ABI (include/hero_hip.h) without torch.distributed: a 1-rank RCCL communicator, the bucket
+    group all-reduce (fp32 + bf16 in one group), broadcast, all-gather - and the same all-reduce forked onto the
+    communicator's side stream inside a hipGraph capture (no capture_error_mode, no watchdog: the collective is an ordinary
+    node of the captured stream)."""
+    import torch
+    from hero_amd.utils import comm
+    c = comm.Communicator()
+    try:
+        assert (c.rank, c.world) == (0, 1)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        a = torch.randn(1 << 20, device="cuda", generator=g)
+        b = torch.randn(12345, device="cuda", generator=g).bfloat16()
+        a0, b0 = a.clone(), b.clone()
+        c.allreduce_buckets([a, b])
+        c.broadcast(a, 0)
+        ga = c.allgather(b)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a0) and torch.equal(b, b0) and ga.shape == (1, 12345) and torch.equal(ga[0], b0)
+        # captured: x -> 2x on the main stream, all-reduce of x on the side stream (fork / join), then x + 1
+        x = torch.ones(1 << 16, device="cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(graph, stream=s):
+                x.mul_(2.0)
+                c.fork()
+                c.allreduce_buckets([x], stream=c.stream)
+                c.join()
+                x.add_(1.0)
+        torch.cuda.current_stream().wait_stream(s)
+        x.fill_(1.0)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(x, torch.full_like(x, 15.0))          # ((1*2+1)*2+1)*2+1
+        # error behaviour of the boundary: bad arguments come back as codes with a message, nothing is enqueued
+        from hero_amd import _lib as L
+        import ctypes as C
+        arr = (L.CommBucket * 1)()
+        assert L.lib().hero_comm_allreduce_buckets(c._h, arr, 1, None) != 0 and b"bad bucket" in L.lib().hero_last_error()
+        assert L.lib().hero_comm_broadcast(c._h, L.ptr(a), 4, 3, None) != 0
+        assert L.lib().hero_comm_allreduce_buckets(None, arr, 1, None) != 0
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("wire", ["none", "bf16"])
+def test_one_rank_gradient_exchange_through_the_c_abi(tmp_path, wire):
+    """HERO_COMM=1: the gradient buckets of the data-parallel step travel through hero_comm_allreduce_buckets on the
+    communicator's side stream (forked at the bucket's finality point, joined in finish()) instead of the process group;
+    the worker checks bucketed all-reduce == sum of the local gradients and that optimiser steps stay finite."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1", HERO_COMM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29561",
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), wire, "nccl"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.load(open(tmp_path / "rank0.json"))
+    assert res["exchange"] == "abi" and res["collectives"] and res["buckets"] > 3
+
+
+def test_bench_one_rank_exchange_through_the_c_abi_captured_in_a_hipgraph():
+    """bench.py with HERO_COMM=1: eager run, then the step captured WITH its hero_comm all-reduces; the comm block names
+    the exchange."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1", HERO_COMM="1",
+               HERO_DP_GRAPH="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29563", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print("hero_comm one rank:", out["config"]["launch"], out["ms_per_step"], out["comm"])
+    assert out["comm"]["exchange"].startswith("hero_comm") and out["comm"]["ranks_seen"] == 1
+    assert out["final_loss"] == out["final_loss"] and out["value"] > 0
+    assert out["config"]["launch"].startswith("hipGraph replay (step captured")

@@ -15,6 +15,10 @@ done
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_D4 -o s -- python $R/bench.py --workload D4 --videos 256 --steps 2 --warmup 2 > /dev/null 2> $R/$OUT/${TAG}_stats_D4.log)
 python tools/profile_summary.py stats $OUT/${TAG}_stats_D4 6 $OUT/${TAG}_kernel_stats_D4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload D4 --videos 256 --steps 2 --warmup 2 (MI355X; 256 videos x 256 frames per step)"
 find $OUT/${TAG}_stats_D4 -name "*kernel_trace.csv" -delete
+# idle time between the kernels of the hipGraph replay (tools/lab/graph_gaps.py)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/${TAG}_gaps -o g -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > /dev/null 2> $R/$OUT/${TAG}_gaps.log)
+python tools/lab/graph_gaps.py $OUT/${TAG}_gaps > $OUT/${TAG}_graph_gaps.txt 2>&1
+find $OUT/${TAG}_gaps -name "*kernel_trace.csv" -delete
 # the line reads its counters from profiles/ (stamped with the kernel-source hash): the passes of THIS call
 cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_mfma.json profiles/
 (timeout 600 python bench.py --steps 20 --warmup 4) > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

@@ -26,7 +26,7 @@ EXPORTS = [
     "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
     "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats", "hero_derive_multi",
     "hero_comm_available", "hero_comm_unique_id", "hero_comm_init", "hero_comm_destroy", "hero_comm_rank", "hero_comm_world",
-    "hero_comm_allreduce_buckets", "hero_comm_broadcast", "hero_comm_allgather",
+    "hero_comm_allreduce_buckets", "hero_comm_broadcast", "hero_comm_allgather", "hero_comm_allgather_var",
 ]
 
 
@@ -244,6 +244,7 @@ def lib():
         L.hero_comm_allreduce_buckets.argtypes = [C.c_void_p, C.POINTER(CommBucket), C.c_int, C.c_void_p]
         L.hero_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.hero_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.hero_comm_allgather_var.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
         _lib = L
     return _lib
 

@@ -154,3 +154,25 @@ extern "C" int hero_comm_allgather(void* comm, const void* send, void* recv, siz
   const int rc = api().AllGather(send, recv, bytes_per_rank, kInt8, s->comm, static_cast<hipStream_t>(stream));
   return rc ? fail("hero_comm_allgather", rc) : HERO_OK;
 }
+
+// recv = rank 0's bytes, rank 1's bytes, ... back to back (bytes_per_rank[world], host array, the same on every rank): the
+// variable-length gather of the cross-GPU negatives without padding to the longest rank (model/pretrain.py:383-401 pads,
+// gathers and slices); one broadcast per rank inside ONE RCCL group.
+extern "C" int hero_comm_allgather_var(void* comm, const void* send, void* recv, const size_t* bytes_per_rank, hero_stream_t stream) {
+  HERO_COMM_READY(comm);
+  HERO_REQUIRE(recv && bytes_per_rank, "hero_comm_allgather_var: null pointer");
+  State* s = static_cast<State*>(comm);
+  HERO_REQUIRE(bytes_per_rank[s->rank] == 0 || send, "hero_comm_allgather_var: null send buffer");
+  int rc = api().GroupStart();
+  if (rc) return fail("hero_comm_allgather_var(group)", rc);
+  size_t off = 0;
+  for (int r = 0; r < s->world && !rc; ++r) {
+    const size_t n = bytes_per_rank[r];
+    if (n) rc = api().Broadcast(r == s->rank ? send : static_cast<const char*>(recv) + off, static_cast<char*>(recv) + off, n, kInt8, r, s->comm,
+                                static_cast<hipStream_t>(stream));
+    off += n;
+  }
+  const int rc2 = api().GroupEnd();
+  if (rc || rc2) return fail("hero_comm_allgather_var", rc ? rc : rc2);
+  return HERO_OK;
+}

@@ -72,6 +72,18 @@ class Communicator:
                                             self._s(stream)))
         return out
 
+    def allgather_var(self, send, dims, stream=None):
+        """cat of the ranks' `send` tensors along dim 0; dims[r] = rank r's dim-0 size (host ints, equal on every rank)."""
+        row = send.element_size()
+        for d in send.shape[1:]:
+            row *= int(d)
+        out = send.new_empty((sum(dims),) + tuple(send.shape[1:]))
+        if out.numel() == 0:
+            return out
+        arr = (C.c_size_t * self.world)(*[int(d) * row for d in dims])
+        L.check(L.lib().hero_comm_allgather_var(self._h, L.ptr(send) if send.numel() else None, L.ptr(out), arr, self._s(stream)))
+        return out
+
     # fork / join of the side stream against the current one (captured as graph dependencies under stream capture)
     def fork(self):
         self.stream.wait_stream(torch.cuda.current_stream(self.device))

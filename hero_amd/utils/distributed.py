@@ -389,16 +389,15 @@ class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tensor, dims):
         r, n = rank(), world_size()
+        ctx.offset, ctx.dim = sum(dims[:r]), tensor.shape[0]
+        if _abi_on(tensor):
+            from . import comm                      # no padding, no cat: the ranks' rows land back to back (current stream)
+            return comm.communicator().allgather_var(tensor.contiguous(), dims)
         mx = max(dims)
         buf = tensor.new_zeros((mx,) + tuple(tensor.shape[1:]))
         buf[:tensor.shape[0]] = tensor
-        if _abi_on(buf):
-            from . import comm
-            out = comm.communicator().allgather(buf.contiguous())        # enqueued on the current stream
-        else:
-            out = [torch.empty_like(buf) for _ in range(n)]
-            dist.all_gather(out, buf.contiguous())
-        ctx.offset, ctx.dim = sum(dims[:r]), tensor.shape[0]
+        out = [torch.empty_like(buf) for _ in range(n)]
+        dist.all_gather(out, buf.contiguous())
         return torch.cat([o[:d] for o, d in zip(out, dims)], dim=0)
 
     @staticmethod

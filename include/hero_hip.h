@@ -569,6 +569,9 @@ int hero_comm_world(void* comm);
 int hero_comm_allreduce_buckets(void* comm, const HeroCommBucket* buckets, int n, hero_stream_t stream);  /* SUM, <= 64 buckets, one group */
 int hero_comm_broadcast(void* comm, void* buf, size_t bytes, int root, hero_stream_t stream);
 int hero_comm_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hero_stream_t stream);
+/* recv = the ranks' buffers back to back; bytes_per_rank[world] is a HOST array, equal on every rank (the padded gather   */
+/* + slice of model/pretrain.py:383-401 as one group of broadcasts)                                                       */
+int hero_comm_allgather_var(void* comm, const void* send, void* recv, const size_t* bytes_per_rank, hero_stream_t stream);
 
 #ifdef __cplusplus
 }

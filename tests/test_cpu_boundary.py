@@ -454,6 +454,7 @@ def test_hero_comm_boundary_without_a_gpu(built_lib):
     assert L.hero_comm_allreduce_buckets(None, arr, 1, None) != 0 and b"hero_comm" in L.hero_last_error()
     assert L.hero_comm_broadcast(None, None, 0, 0, None) != 0
     assert L.hero_comm_allgather(None, None, None, 0, None) != 0
+    assert L.hero_comm_allgather_var(None, None, None, None, None) != 0
     if L.hero_comm_available():
         uid = (C.c_char * 128)()
         assert L.hero_comm_unique_id(uid) == 0 and any(uid.raw)

@@ -136,8 +136,12 @@ def test_hero_comm_abi_collectives_one_rank_eager_and_captured():
         c.allreduce_buckets([a, b])
         c.broadcast(a, 0)
         ga = c.allgather(b)
+        rows = torch.arange(7 * 5, device="cuda").view(7, 5)                  # int64 rows: the masks of the negatives
+        gv = c.allgather_var(rows, [7])
+        ge = c.allgather_var(rows[:0], [0])
         torch.cuda.synchronize()
         assert torch.equal(a, a0) and torch.equal(b, b0) and ga.shape == (1, 12345) and torch.equal(ga[0], b0)
+        assert torch.equal(gv, rows) and ge.shape == (0, 5)
         # captured: x -> 2x on the main stream, all-reduce of x on the side stream (fork / join), then x + 1
         x = torch.ones(1 << 16, device="cuda")
         s = torch.cuda.Stream()

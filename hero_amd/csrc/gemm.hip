@@ -1060,7 +1060,7 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
 
 // Tuning hook: force a tile geometry (0: 128x128, 1: 192x128, 2: 256x256, 3: 64x64 [1 and 3: direct-to-LDS path only], -1: heuristic).
 extern "C" int hero_gemm_force_config(int cfg) {
-  if (cfg >= 8 && cfg <= 12) {     // wave-specialised kernels never / always 192 x 192 / always 128 x 192 (4-wave heuristic otherwise); 11 / 12: the latter two with the deferred epilogue
+  if (cfg >= 8 && cfg <= 14) {     // 13 / 14: the 64 x 128 / 64 x 192 wave-specialised geometries (small-M, long-K GEMMs)     // wave-specialised kernels never / always 192 x 192 / always 128 x 192 (4-wave heuristic otherwise); 11 / 12: the latter two with the deferred epilogue
     g_force_cfg = cfg;
     g_use_glds = 1;
     g_group = 0;

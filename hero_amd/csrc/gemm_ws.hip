@@ -66,10 +66,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   if (wave >= 4) {
     // ------------------------------------------------------------------ loader waves
+    // The ring holds NSG stages: NSG - 1 are issued ahead, the wave then always waits until all but the NSG - 2 youngest
+    // have landed (VMEM operations of a wave complete in order), i.e. until the stage the compute waves read next is in.
     Loader<G, TR> ld(g, smem, wg, nwg, wave - 4, lane);
-    ld.issue();
-    const bool second = ld.issue();
-    if (second) wait_vm<G::PW>(); else wait_vm<0>();
+    constexpr int AHEAD = (G::NSG - 2) * G::PW;
+    bool more = ld.issue();
+#pragma unroll
+    for (int k = 0; k < G::NSG - 2; ++k) more = ld.issue();
+    if (more) wait_vm<AHEAD>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                                     // B(-1): stage 0 landed
     unsigned slot = 0;
     int item_no = 0;
@@ -77,13 +81,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const Item ic = item_coord<G>(g, cit);
       WS_T(item_no, 0, wave, lane);
       for (int t = 0; t < ic.nk; ++t) {
-        if (ld.issue()) wait_vm<G::PW>(); else wait_vm<0>();          // stage u+2 issued, stage u+1 landed
+        if (ld.issue()) wait_vm<AHEAD>(); else wait_vm<0>();          // stage u + NSG - 1 issued, stage u + 1 landed
         __builtin_amdgcn_s_barrier();                                 // B(u)
-        if (t + 1 < ic.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
+        if (t + 1 < ic.nk) { slot += G::STAGE; if (slot == G::NSG * G::STAGE) slot = 0; }
       }
       WS_T(item_no, 1, wave, lane);
       if constexpr (!TR) epilogue_rows<G, EK, false>(g, ic, smem, slot, nullptr, wave, lane, item_no);
-      slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0;
+      slot += G::STAGE; if (slot == G::NSG * G::STAGE) slot = 0;
     }
     return;
   }
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const char* cur = smem + curo;
       last = curo;
       curo += G::STAGE;
-      if (curo == NS * G::STAGE) curo = 0;
+      if (curo == G::NSG * G::STAGE) curo = 0;
       const char* nxt = smem + curo;
       // one scheduling region per 16-k slice: the fragment reads of the NEXT slice are spread between the MFMAs of the
       // current one (round 3; as a block in front of them they cost MFMA-idle issue time, see gemm_wsb_kernel)
@@ -933,6 +937,10 @@ static int launch_kk(const WsArgs& g, hipStream_t s) {
   if (e.act == HERO_ACT_NONE && b && !r && !d) return launch<TM, TN, false, EK_BIAS>(g, TM == 3 ? 8 : 10, s);
   if (e.act == HERO_ACT_NONE && b && r) return launch<TM, TN, false, EK_BIAS | EK_RES | EK_DROP>(g, TM == 3 ? 8 : 10, s);
   if ((e.act == HERO_ACT_GELU || e.act == HERO_ACT_GELU_DG) && b && !r && !d) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, TM == 3 ? 8 : 10, s);
+  if (e.act == HERO_ACT_RELU && b && !r && !d && e.aux) return launch<TM, TN, false, EK_BIAS | EK_GELU>(g, TM == 3 ? 8 : 10, s);
+  if constexpr (TM == 1) {         // LinearLayer (frame_transform, model/layers.py:86-93 + model/model.py:211-212): relu(x W^T + b) + matched features
+    if (e.act == HERO_ACT_RELU && b && r && !d && e.aux) return launch<TM, TN, false, EK_BIAS | EK_GELU | EK_RES>(g, 10, s);
+  }
   if (e.act == HERO_ACT_NONE && !b && !r && !d) return launch<TM, TN, false, 0>(g, TM == 3 ? 8 : 10, s);
   if (e.act == HERO_ACT_NONE && !b && r && !d) return launch<TM, TN, false, EK_RES>(g, TM == 3 ? 8 : 10, s);
   if ((e.act == HERO_ACT_GELU_BWD || e.act == HERO_ACT_MUL_AUX) && !b && !r && !d) return launch<TM, TN, false, EK_GELU_BWD>(g, TM == 3 ? 8 : 10, s);
@@ -946,6 +954,12 @@ template <int TM, int TN> int launch_kk_deferred(const WsArgs& g, hipStream_t s)
 // SLOWER than the in-line one on every epilogue that has arithmetic (bit-equal results).  The loader waves have no slack:
 // they sit in the issue of the 12 DMA pieces of a step for ~1200 of its ~1660 cycles (the L2 -> LDS fill is as critical
 // as the MFMAs), so every VALU instruction and every store they carry delays the ring.  HERO_WS_DEFER=1 / force 11, 12.
+// 64-row geometries for small-M GEMMs with long reductions (HERO_WS_SMALL_M=0: the 4-wave kernels of rounds 1-3)
+static bool small_m_default() {
+  static const bool on = [] { const char* v = getenv("HERO_WS_SMALL_M"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
 static bool defer_default() {
   static const bool on = [] { const char* v = getenv("HERO_WS_DEFER"); return v && v[0] == '1'; }();
   return on;
@@ -962,7 +976,7 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
                 int b_layout, const HeroGemmEpilogue& epi, int force_cfg, hipStream_t s) {
   using namespace ws;
   if (force_cfg == 8) return -1;
-  if (force_cfg != 9 && force_cfg != 10 && force_cfg != 11 && force_cfg != 12 && force_cfg != -1) return -1;      // a forced 4-wave geometry
+  if ((force_cfg < 9 || force_cfg > 14) && force_cfg != -1) return -1;      // a forced 4-wave geometry
   const int force_cfg_in = force_cfg;
   const bool defer = force_cfg == -1 && defer_default();
   if (force_cfg == 11) force_cfg = 9;
@@ -972,7 +986,7 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
   const bool oo = a_layout == HERO_LAYOUT_O && b_layout == HERO_LAYOUT_O;
   if (!kk && !oo) return -1;
   if (K < 64 || N % 8 != 0 || M < 8) return -1;
-  if (force_cfg == 10 && !kk) return -1;
+  if ((force_cfg == 10 || force_cfg == 13 || force_cfg == 14) && !kk) return -1;
   WsArgs g;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -1005,6 +1019,25 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
       g.nwork = t23;
       if ((defer && t23 > cus) || force_cfg_in == 12) { const int rc = launch_kk_deferred<2, 3>(g, s); if (rc != -1) return rc; }
       return launch_kk<2, 3>(g, s);
+    }
+    // Under half a round of 192 x 192 tiles - the Temporal Transformer's 1920 rows into N = 768: 40 tiles - the 64-row
+    // geometries: 64 x 128 tiles (180 workgroups, 24 KB per step, a 6-deep ring so that as many bytes are in flight as the
+    // large tiles keep with three stages).  The 4-wave 64 x 64 kernels put 360 workgroups of 16 KB steps on 256 CUs and are
+    // bound by the busiest CU's L2 -> LDS fill (two tiles x 48 steps: 26 us at K = 3072, the vendor library 17.7,
+    // profiles/r04_vs_library.txt); 18.2 us with this geometry, 6.7 vs 8.0 at K = 768 (tools/lab/smallm_ws.py).
+    if (force_cfg == 13 || force_cfg == 14 || (force_cfg == -1 && small_m_default() && ntile * 2 < cus && K >= 512)) {
+      typedef Geo<1, 2> G12;
+      typedef Geo<1, 3> G13;
+      const int rows64 = (M + 63) / 64;
+      const int t12 = rows64 * ((N + G12::BN - 1) / G12::BN), t13 = rows64 * g.tiles_n;
+      if (force_cfg == 14) {
+        g.tiles_m = rows64; g.nwork = t13;
+        return launch_kk<1, 3>(g, s);
+      }
+      if (force_cfg == 13 || (t12 * 2 >= cus && t12 <= cus)) {
+        g.tiles_m = rows64; g.tiles_n = (N + G12::BN - 1) / G12::BN; g.nwork = t12;
+        return launch_kk<1, 2>(g, s);
+      }
     }
     // worth it from about half a round of tiles; below that the 4-wave 64 x 64 / 128 x 128 tiles fill the chip better
     if (force_cfg != 9 && ntile * 2 < cus) return -1;

@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
-constexpr int NS = 3;                 // ring stages
+constexpr int NS = 3;                 // ring stages of the 192 x 192 / 128 x 192 geometries (Geo::NSG: per geometry)
 constexpr int SPARE_OFF = 144 * 1024; // 16 KiB behind the largest ring: column-sum fold
 
 // Cache policy of the epilogue stores (buffer-store aux bits; 2 = nt: streaming, no allocation priority in the L2).
@@ -89,8 +89,12 @@ template <int TM_, int TN_> struct Geo {
   static constexpr int RPP = (STAGE / ROWB >= 64 && BM % 64 == 0) ? 64 : 32;   // rows per epilogue pass
   static constexpr int PASSES = BM / RPP;
   static constexpr int C8 = BN / 8, RPI = 512 / C8, ITERS = (RPP + RPI - 1) / RPI;
-  static constexpr int LDS = NS * STAGE > SPARE_OFF ? NS * STAGE : SPARE_OFF + 16384;
-  static_assert(NS * STAGE <= SPARE_OFF && RPP * ROWB <= STAGE && RPI * BN * 4 <= 16384, "LDS budget");
+  // ring depth: what fits under the spare region, at most 6.  The 64-row geometries (small-M GEMMs) move 24-32 KB per step
+  // and need the deeper ring to keep as many bytes in flight as the large tiles do with three stages.
+  static constexpr int NSG = SPARE_OFF / STAGE > 6 ? 6 : SPARE_OFF / STAGE;
+  static constexpr int LDS = SPARE_OFF + 16384;
+  static_assert(NSG >= 3 && NSG * STAGE <= SPARE_OFF && RPP * ROWB <= STAGE && RPI * BN * 4 <= 16384 && (NSG - 2) * PW < 64, "LDS budget");
+  static_assert(TM_ < 2 || NSG == NS, "the large geometries keep the three-stage ring");
 };
 
 struct Item { int m0, n0, kbeg, nk; };
@@ -198,7 +202,7 @@ struct Loader {
     for (int i = 0; i < G::PB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, HERO_LDS_PTR(buf + G::A_BYTES + (w * G::PB + i) * 1024), 16, gob[i], 0, 0, HERO_WS_LOAD_AUX_B);
     fill += G::STAGE;
-    if (fill == NS * G::STAGE) fill = 0;
+    if (fill == G::NSG * G::STAGE) fill = 0;
     if (++ik == ic.nk) {
       item += nwg;
       ik = 0;
@@ -254,6 +258,7 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
   }
   const bool do_csum = (EK & EK_GELU_BWD) && e.colsum != nullptr;
   const bool save_dg = (EK & EK_GELU) && e.act == HERO_ACT_GELU_DG, mul_aux = (EK & EK_GELU_BWD) && e.act == HERO_ACT_MUL_AUX;
+  const bool relu = (EK & EK_GELU) && e.act == HERO_ACT_RELU;      // uniform: the activation-with-saved-value instantiations serve ReLU too
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
   // A pass stages 64 rows.  With three passes over a 192-row tile the two 32-row blocks of a pass are taken from the
@@ -322,6 +327,10 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
 #pragma unroll
             for (int k = 0; k < 8; ++k) gelu_both<bf16_t>(v[k], v[k], dg[k]);
             u.x = f2bf_pk(dg[0], dg[1]); u.y = f2bf_pk(dg[2], dg[3]); u.z = f2bf_pk(dg[4], dg[5]); u.w = f2bf_pk(dg[6], dg[7]);
+          } else if (relu) {                            // HERO_ACT_RELU: aux <- relu(acc + bias), the value before the residual
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
           } else {
             u.x = f2bf_pk(v[0], v[1]); u.y = f2bf_pk(v[2], v[3]); u.z = f2bf_pk(v[4], v[5]); u.w = f2bf_pk(v[6], v[7]);
 #pragma unroll

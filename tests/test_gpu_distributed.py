@@ -100,7 +100,13 @@ def test_bench_one_rank_over_rccl_captured_in_a_hipgraph():
     assert e["config"]["launch"] == "eager" and "graph_ms_per_step" not in e["config"]
     assert g["final_loss"] == g["final_loss"]
     print("RCCL one rank:", g["config"]["launch"], g["ms_per_step"], {k: v for k, v in g["config"].items() if k.endswith("_ms_per_step")})
-    assert g["config"]["launch"].startswith("hipGraph replay (step captured") and g["config"]["eager_ms_per_step"] >= g["ms_per_step"]
+    # the line reports the faster of the two measured runs and keeps the other one's time: on most boxes the replay wins
+    # (eager is host-bound), on a box with a fast host the two are within noise - either way both times are on the line
+    assert g["comm"]["graph_ms_per_step"] is not None and g["comm"]["graph_ms_per_step"] > 0
+    if g["config"]["launch"].startswith("hipGraph replay (step captured"):
+        assert g["config"]["eager_ms_per_step"] >= g["ms_per_step"]
+    else:
+        assert g["config"]["launch"] == "eager" and g["config"]["graph_ms_per_step"] >= g["ms_per_step"]
 
 
 def test_bench_wedged_capture_falls_back_to_the_eager_line():
@@ -200,4 +206,4 @@ def test_bench_one_rank_exchange_through_the_c_abi_captured_in_a_hipgraph():
     print("hero_comm one rank:", out["config"]["launch"], out["ms_per_step"], out["comm"])
     assert out["comm"]["exchange"].startswith("hero_comm") and out["comm"]["ranks_seen"] == 1
     assert out["final_loss"] == out["final_loss"] and out["value"] > 0
-    assert out["config"]["launch"].startswith("hipGraph replay (step captured")
+    assert out["comm"]["graph_ms_per_step"] is not None and out["config"]["launch"].startswith(("hipGraph replay (step captured", "eager"))

@@ -122,6 +122,52 @@ def test_gemm_wave_specialised_128x192_tiles(HF, Lb, M, N, K):
     _ws_against_4wave(HF, Lb, M, N, K, 10)
 
 
+@pytest.mark.parametrize("M,N,K,cfg", [(1920, 768, 3072, 13), (1920, 768, 768, 13), (2497, 776, 1536, 13), (1920, 768, 4352, 13), (130, 136, 64, 13),
+                                       (5000, 768, 768, 13), (1920, 768, 3072, 14), (1000, 392, 640, 14), (3000, 3072, 768, 14)])
+def test_gemm_wave_specialised_64_row_tiles(HF, Lb, M, N, K, cfg):
+    """The 64-row geometries of the wave-specialised kernel (round 4: Geo<1, 2> = 64 x 128 tiles with a SIX-deep ring,
+    Geo<1, 3> = 64 x 192 with four stages) that the Temporal Transformer's 1920-row GEMMs into N = 768 take: the six fused
+    epilogues against the 4-wave kernels and fp32 torch, row / column tails, a single k-step (K = 64 - fewer stages than the
+    ring is deep), more tiles than workgroups (5000 x 768: 474 tiles), and the ReLU epilogue of `frame_transform`
+    (relu(x W^T + b) saved, + residual: model/layers.py:86-93, model/model.py:211-212)."""
+    _ws_against_4wave(HF, Lb, M, N, K, cfg, colsum=False)
+    dtype = torch.bfloat16
+    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
+    res = rnd(M, N, dtype=dtype, seed=4)
+    outs = []
+    for c in (cfg, 8):
+        Lb.lib().hero_gemm_force_config(c)
+        try:
+            a1, a2 = (torch.empty((M, N), dtype=dtype, device=x.device) for _ in range(2))
+            outs.append([HF.k_linear(x, w, b, act=Lb.ACT_RELU, aux=a1), a1, HF.k_linear(x, w, b, act=Lb.ACT_RELU, aux=a2, residual=res), a2])
+        finally:
+            Lb.lib().hero_gemm_force_config(-1)
+    ref = torch.relu(x.float() @ w.float().t() + b)
+    sc = math.sqrt(K) * 0.05
+    close(outs[0][0], ref, dtype, scale=sc)
+    close(outs[0][1], ref, dtype, scale=sc)
+    close(outs[0][3], ref, dtype, scale=sc)
+    close(outs[0][2], ref + res.float(), dtype, scale=sc + 1)
+    for a_, b_ in zip(*outs):
+        close(a_, b_, dtype, scale=sc + 1)
+    assert ((outs[0][1] == 0) != (outs[1][1] == 0)).float().mean().item() < 1e-3      # the same elements are clipped
+
+
+def test_gemm_small_m_heuristic_takes_the_64_row_tiles(HF, Lb):
+    """hero_gemm's own choice for M = 1920, N = 768 (K >= 512) is the 64 x 128 geometry: bit-equal to forcing it, and
+    HERO_WS_SMALL_M is the documented switch back (read once per process, so only the default is checked here)."""
+    dtype = torch.bfloat16
+    for K in (768, 3072):
+        x, w, b = rnd(1920, K, dtype=dtype, seed=1), rnd(768, K, dtype=dtype, seed=2, scale=0.05), rnd(768, seed=3)
+        y = HF.k_linear(x, w, b)
+        Lb.lib().hero_gemm_force_config(13)
+        try:
+            y13 = HF.k_linear(x, w, b)
+        finally:
+            Lb.lib().hero_gemm_force_config(-1)
+        assert torch.equal(y, y13)
+
+
 @pytest.mark.parametrize("M,N,K,cfg", [(12000, 2304, 768, 11), (2500, 3072, 768, 11), (7000, 776, 1024, 11), (5000, 3072, 768, 12),
                                        (1000, 392, 640, 12), (12000, 768, 3072, 11)])
 def test_gemm_wave_specialised_deferred_epilogue(HF, Lb, M, N, K, cfg):

@@ -997,6 +997,119 @@ static int dispatch(const GemmArgs& g, int al, int bl, int cfg, hipStream_t s) {
 
 using namespace hero;
 
+// ---------------------------------------------------------------------------------------------
+// Skinny fp32 GEMM: C[M <= 32, N] = A[M, K] B[N, K]^T (+ bias).  The loss head's fp32 Linear layers on the 32 query vectors
+// (model/pretrain.py:128-166, model/encoder.py:426-485) are 32 x 768 x 768 / 32 x 1920 x 768: on the 64 x 64 MFMA tiles
+// that is 12-30 workgroups walking 384 fp32 k-steps alone - 22 us per launch, three per micro-step.  Here: one wave per
+// TWO output columns, every lane owns a 4-wide slice of the reduction per 256-k block (coalesced float4 loads of the weight
+// rows and of the 32 activation rows, all independent -> one memory round trip), 64 fmaf chains per lane, a butterfly
+// reduction per output; fixed order = bit-reproducible; ~96-240 workgroups.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes of a wave, valid in lane 63 (fixed order)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0xb1, 0xf>(v);      // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);      // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);     // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);     // row_ror:8   -> every lane of a 16-lane row holds the row's sum
+  v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_skinny_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                              const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc) {
+  // The activation rows go through the LDS (one cooperative copy per 1024-k chunk: a single memory round trip for the
+  // workgroup, then ~100-cycle reads) - read straight from the L2 by every wave the three 256-k blocks of K = 768 were
+  // three serial L2 round trips of 34 loads each (14 us per launch instead of 22; with the LDS copy ~6).
+  extern __shared__ __attribute__((aligned(16))) char smem_skinny[];
+  float* xs = reinterpret_cast<float*>(smem_skinny);
+  constexpr int KC = 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 2;
+  const bool live = n0 < N, two = n0 + 1 < N;
+  float acc0[32], acc1[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) acc0[m] = acc1[m] = 0.f;
+  const float* b0 = B + (size_t)(live ? n0 : 0) * ldb;
+  const float* b1 = B + (size_t)(two ? n0 + 1 : (live ? n0 : 0)) * ldb;
+  for (int kc = 0; kc < K; kc += KC) {
+    const int kw = min(KC, K - kc);                       // multiple of 4
+    // this lane's weight slices of the chunk first (up to 4 x 2 float4): they come from HBM once per launch and their
+    // latency is the kernel's critical path - in flight while the activation rows are copied
+    float4 w0[4], w1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = min(lane * 4 + j * 256, kw - 4);
+      w0[j] = *reinterpret_cast<const float4*>(b0 + kc + k);
+      w1[j] = *reinterpret_cast<const float4*>(b1 + kc + k);
+    }
+    if (kc) __syncthreads();
+    // Thread t copies the float4 at k = 4 t of every row: 16 loads in flight, then 16 LDS stores, twice.  Branch-free
+    // (threads past the chunk's width load column 0 and store into a dummy slot behind the rows): with a branch around
+    // each store hipcc sinks the load next to it and waits for every round trip - 24 serial L2 latencies for K = 768.
+    {
+      const int k = threadIdx.x * 4;
+      const bool in = k < kw;
+      const float* src = A + kc + (in ? k : 0);
+      float* dst = in ? xs + k : xs + 32 * kw;
+      const int dstride = in ? kw : 0;
+#pragma unroll
+      for (int m0 = 0; m0 < 32; m0 += 16) {
+        float4 t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = *reinterpret_cast<const float4*>(src + (size_t)(m0 + j < M ? m0 + j : M - 1) * lda);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<float4*>(dst + (m0 + j) * dstride) = t[j];
+      }
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = lane * 4 + j * 256;
+        if (k < kw) {
+          // sixteen LDS reads issued as a block, then their 128 FMAs (left to itself hipcc waits for every read before the
+          // FMAs that use it: 128 serial LDS latencies per chunk, 7 of the kernel's 11 us)
+#pragma unroll
+          for (int m0 = 0; m0 < 32; m0 += 16) {
+            float4 xv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xv[q] = *reinterpret_cast<const float4*>(xs + (m0 + q) * kw + k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float4 x = xv[q];
+              acc0[m0 + q] = fmaf(x.w, w0[j].w, fmaf(x.z, w0[j].z, fmaf(x.y, w0[j].y, fmaf(x.x, w0[j].x, acc0[m0 + q]))));
+              acc1[m0 + q] = fmaf(x.w, w1[j].w, fmaf(x.z, w1[j].z, fmaf(x.y, w1[j].y, fmaf(x.x, w1[j].x, acc1[m0 + q]))));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  }
+  if (!live) return;
+  // 64 wave-wide sums: DPP adds inside the VALU (quad swaps, row rotations, the two row broadcasts; the total ends up in
+  // lane 63) - as __shfl_xor butterflies they were 384 ds_bpermute round trips, most of the kernel's 14 us.
+  // lane m stores row m: pick its value without dynamic register indexing
+  float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_lane63(acc0[m])), 63));
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_lane63(acc1[m])), 63));
+    v0 = lane == m ? s0 : v0;
+    v1 = lane == m ? s1 : v1;
+  }
+  if (lane < M) {
+    C[(size_t)lane * ldc + n0] = v0 + (bias ? bias[n0] : 0.f);
+    if (two) C[(size_t)lane * ldc + n0 + 1] = v1 + (bias ? bias[n0 + 1] : 0.f);
+  }
+}
+
 extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int a_layout, int b_layout, int dtype, const HeroGemmEpilogue* epi, hero_stream_t stream) {
   HERO_REQUIRE(A && B && C && epi, "hero_gemm: null pointer");
@@ -1027,6 +1140,20 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   const int bk = dtype == HERO_BF16 ? 64 : 32;
   const bool k_contig = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == HERO_F32 && k_contig && M <= 32 && K >= 256 && g_force_cfg == -1 && epi->act == HERO_ACT_NONE && !epi->residual && !epi->colsum &&
+      !epi->out_f32 && epi->split_k <= 1 && epi->dropout.threshold16 == 0) {
+    void* tok = gemm_prof_begin(3, s);
+    const int lds = 32 * (K < 1024 ? K : 1024) * 4 + 16;       // + the dummy slot of the copy
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024 * 4 + 16);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((N + 7) / 8), dim3(256), lds, s, static_cast<const float*>(A), static_cast<const float*>(B),
+                       static_cast<float*>(C), epi->bias, M, N, K, lda, ldb, ldc);
+    gemm_prof_end(tok, 2.0 * (double)M * (double)N * (double)K, s);
+    return check_launch("hero_gemm(skinny f32)");
+  }
   if (dtype == HERO_BF16) {        // large problems: wave-specialised persistent 192 x 192 tiles (gemm_ws.hip)
     const int rc = gemm_ws_run(A, B, C, M, N, K, lda, ldb, ldc, a_layout, b_layout, *epi, g_force_cfg, s);
     if (rc != -1) return rc;

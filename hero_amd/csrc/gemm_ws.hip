@@ -1030,11 +1030,13 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
       typedef Geo<1, 3> G13;
       const int rows64 = (M + 63) / 64;
       const int t12 = rows64 * ((N + G12::BN - 1) / G12::BN), t13 = rows64 * g.tiles_n;
-      if (force_cfg == 14) {
+      // 64 x 192 (four stages) where 64 x 128 tiles would spill into a second round: the ragged batch's ~3100 padded frame rows
+      // (49 x 6 = 294 tiles against 49 x 4 = 196); per tile it is ~20 % behind 64 x 128, a partial second round costs more
+      if (force_cfg == 14 || (force_cfg == -1 && t12 > cus && t13 <= cus)) {
         g.tiles_m = rows64; g.nwork = t13;
         return launch_kk<1, 3>(g, s);
       }
-      if (force_cfg == 13 || (t12 * 2 >= cus && t12 <= cus)) {
+      if (force_cfg == 13 || (t12 * 8 >= cus && t12 <= cus)) {        // down to the 480 query rows (48 tiles: 12.0 vs 13.7 us at K = 2304)
         g.tiles_m = rows64; g.tiles_n = (N + G12::BN - 1) / G12::BN; g.nwork = t12;
         return launch_kk<1, 2>(g, s);
       }

@@ -153,6 +153,25 @@ def test_gemm_wave_specialised_64_row_tiles(HF, Lb, M, N, K, cfg):
     assert ((outs[0][1] == 0) != (outs[1][1] == 0)).float().mean().item() < 1e-3      # the same elements are clipped
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 768, 768), (32, 1920, 768), (5, 772, 260), (1, 8, 256), (32, 1000, 3072)])
+def test_gemm_skinny_f32(HF, Lb, M, N, K):
+    """The fp32 Linear layers of the loss head on <= 32 rows (queries): the skinny kernel (one wave per two output columns,
+    fixed-order reduction) against fp32 torch and the MFMA tiles, with and without bias, odd column counts, a ragged last
+    256-k block; bit-reproducible."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    ref = x.double() @ w.double().t()
+    y0, y1 = HF.k_linear(x, w), HF.k_linear(x, w, b)
+    torch.testing.assert_close(y0.double(), ref, rtol=1e-5, atol=1e-5 * math.sqrt(K))
+    torch.testing.assert_close(y1.double(), ref + b.double(), rtol=1e-5, atol=1e-5 * math.sqrt(K))
+    assert torch.equal(HF.k_linear(x, w, b), y1)
+    Lb.lib().hero_gemm_force_config(3)
+    try:
+        old = HF.k_linear(x, w, b)
+    finally:
+        Lb.lib().hero_gemm_force_config(-1)
+    torch.testing.assert_close(y1, old, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+
+
 def test_gemm_small_m_heuristic_takes_the_64_row_tiles(HF, Lb):
     """hero_gemm's own choice for M = 1920, N = 768 (K >= 512) is the 64 x 128 geometry: bit-equal to forcing it, and
     HERO_WS_SMALL_M is the documented switch back (read once per process, so only the default is checked here)."""

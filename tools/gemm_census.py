@@ -80,7 +80,7 @@ def bench_one(key, cfg, reps=30):
 
 
 LAY = {L.LAYOUT_K: "K", L.LAYOUT_O: "O"}
-print("%6s %6s %6s  lay dt  epilogue                      calls   default  " % ("M", "N", "K") + "  ".join("cfg%d" % c for c in (0, 1, 2, 3, 9, 10)))
+print("%6s %6s %6s  lay dt  epilogue                      calls   default  " % ("M", "N", "K") + "  ".join("cfg%d" % c for c in (0, 1, 3, 8, 10, 13, 14)))
 tot = collections.Counter()
 for key, n in seen.items():
     M, N, K, al, bl, dt, hb, hr, ha, act, of32, beta, split, hd, hc = key
@@ -89,7 +89,7 @@ for key, n in seen.items():
     t0 = bench_one(key, -1)
     forced = []
     if M <= max_m and not of32:
-        for c in (0, 1, 2, 3, 9, 10):
+        for c in (0, 1, 3, 8, 10, 13, 14):
             t = bench_one(key, c)
             forced.append("%6.1f" % t if t is not None else "     -")
     gf = 2.0 * M * N * K / 1e9

@@ -28,7 +28,7 @@ def t(fn, reps=20):
 
 
 print("%6s %5s %5s %-8s  4-wave   64x128   64x192  default  library   (us)   rel.err 4-wave / 64x128 / 64x192" % ("M", "N", "K", "epilogue"))
-for M, N, K in [(1920, 768, 3072), (1920, 768, 2304), (1920, 768, 4352), (1920, 768, 768), (1920, 768, 1536), (2560, 768, 3072), (1000, 768, 3072), (1920, 1024, 4096)]:
+for M, N, K in [(1920, 768, 3072), (1920, 768, 2304), (1920, 768, 4352), (1920, 768, 768), (1920, 768, 1536), (2560, 768, 3072), (1000, 768, 3072), (1920, 1024, 4096), (3104, 768, 768), (3104, 768, 3072), (3104, 768, 2304)]:
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(M, K, device="cuda", generator=g).to(dt); w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(dt)
     b = torch.randn(N, device="cuda", generator=g); res = torch.randn(M, N, device="cuda", generator=g).to(dt)
@@ -43,3 +43,22 @@ for M, N, K in [(1920, 768, 3072), (1920, 768, 2304), (1920, 768, 4352), (1920, 
         L.lib().hero_gemm_force_config(-1)
         lib = t(lambda: F.linear(x, w))
         print("%6d %5d %5d %-8s %7.1f  %7.1f  %7.1f  %7.1f  %7.1f          %.2e / %.2e / %.2e" % (M, N, K, name, *ts, lib, *errs), flush=True)
+
+print("\nfp32, M <= 32 (the loss head's Linear layers): skinny kernel (default) / 64 x 64 MFMA tiles (cfg 3), us")
+for M, N, K in [(32, 768, 768), (32, 1920, 768), (32, 768, 3072)]:
+    x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
+    t_new = t(lambda: HF.k_linear(x, w, b))
+    L.lib().hero_gemm_force_config(3)
+    t_old = t(lambda: HF.k_linear(x, w, b))
+    L.lib().hero_gemm_force_config(-1)
+    print("%4d %5d %5d  %6.1f  %6.1f   library %6.1f" % (M, N, K, t_new, t_old, t(lambda: F.linear(x, w, b))), flush=True)
+
+print("\nM = 480 (queries), bf16: 4-wave / 64x128 / 64x192 / default, us")
+for M, N, K in [(480, 768, 768), (480, 2304, 768), (480, 768, 2304), (480, 3072, 768), (480, 768, 3072)]:
+    x = torch.randn(M, K, device="cuda").to(dt); w = (torch.randn(N, K, device="cuda") * 0.05).to(dt); b = torch.randn(N, device="cuda")
+    ts = []
+    for cfg in (8, 13, 14, -1):
+        L.lib().hero_gemm_force_config(cfg)
+        ts.append(t(lambda: HF.k_linear(x, w, b)))
+    L.lib().hero_gemm_force_config(-1)
+    print("%4d %5d %5d  %6.1f  %6.1f  %6.1f  %6.1f" % (M, N, K, *ts), flush=True)

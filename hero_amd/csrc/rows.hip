@@ -147,7 +147,7 @@ __global__ __launch_bounds__(SORT_NT) void segment_sort_kernel(const int32_t* __
 // workspace (slot 0: the block's first run continues from the previous block, slot 1: its last run continues into the
 // next one), and the second kernel lets the wave of the run's FIRST block add the partials up in block order.
 constexpr int SEG_B = 32;
-constexpr int UNR = 4;        // source rows (and their table rows) in flight per wave
+constexpr int UNR = 8;        // source rows (and their table rows) in flight per wave (4: 32 us per call on the bench batch, eight round trips per wave)
 __device__ __forceinline__ int seg_key(const int32_t* idx, const int32_t* order, int i, int rows, int skip) {
   if (i < 0 || i >= rows) return -2;
   const int v = idx[order[i]];
@@ -241,18 +241,53 @@ __global__ __launch_bounds__(256) void scatter_sorted_fold_kernel(const int32_t*
   const bool whole = seg_key(idx, order, base, rows, skip) == last;
   if (whole && seg_key(idx, order, base - 1, rows, skip) == last) return;
   const int nblk = (rows + SEG_B - 1) / SEG_B;
-  for (int c = lane * 4; c < cols; c += 256) {
-    float4 acc = *reinterpret_cast<const float4*>(partial + ((size_t)blk * 2 + 1) * cols + c);
-    for (int b = blk + 1; b < nblk; ++b) {
-      const float4 v = *reinterpret_cast<const float4*>(partial + ((size_t)b * 2 + 0) * cols + c);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      const int e = min(b * SEG_B + SEG_B, rows);
-      if (seg_key(idx, order, e - 1, rows, skip) != last || seg_key(idx, order, e, rows, skip) != last) break;   // the run ends in block b
+  // How far the run reaches: blocks blk + 1 ... blk + nb start with the run's key (each left its share in slot 0).  64 blocks
+  // are probed per step, one per lane (the serial walk - two dependent index loads and a partial-sum load per block, once
+  // per 256-column chunk - was 18 us for the SEP token's 15 blocks and 50 us for the <mask> token's 45 of the MLM batch).
+  int nb = 0;
+  for (int b0 = blk + 1; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const bool cont = b < nblk && seg_key(idx, order, b * SEG_B, rows, skip) == last;
+    const unsigned long long m = __ballot(cont);
+    const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);
+    nb += run;
+    if (run < 64) break;
+  }
+  constexpr int NCH = 3, FB = 8;                       // 3 x 256 columns per lane pass, 8 partial rows in flight
+  for (int c0 = 0; c0 < cols; c0 += NCH * 256) {
+    float4 acc[NCH];
+    int cc[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      cc[k] = min(c0 + k * 256 + lane * 4, cols - 4);
+      acc[k] = *reinterpret_cast<const float4*>(partial + ((size_t)blk * 2 + 1) * cols + cc[k]);
     }
-    float4* d = reinterpret_cast<float4*>(dst + (size_t)last * cols + c);
-    float4 o = *d;
-    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-    *d = o;
+    for (int b0 = 1; b0 <= nb; b0 += FB) {
+      float4 t[FB][NCH];
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int b = blk + min(b0 + u, nb);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) t[u][k] = *reinterpret_cast<const float4*>(partial + ((size_t)b * 2 + 0) * cols + cc[k]);
+      }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        if (b0 + u <= nb) {                            // uniform; block order = the order of the serial walk
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) { acc[k].x += t[u][k].x; acc[k].y += t[u][k].y; acc[k].z += t[u][k].z; acc[k].w += t[u][k].w; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = c0 + k * 256 + lane * 4;
+      if (c < cols) {
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)last * cols + c);
+        float4 o = *d;
+        o.x += acc[k].x; o.y += acc[k].y; o.z += acc[k].z; o.w += acc[k].w;
+        *d = o;
+      }
+    }
   }
 }
 

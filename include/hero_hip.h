@@ -125,7 +125,11 @@ int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int dtype, con
 int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
                                       * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
                                       * bits 8+: M-tiles per L2 locality group; 8 / 9 / 10: the wave-specialised
-                                      * kernels never / always with 192x192 / always with 128x192 tiles; -1 heuristic */
+                                      * kernels never / always with 192x192 / always with 128x192 tiles; 11 / 12: the
+                                      * latter two with the deferred epilogue; 13 / 14: 64x128 (six-deep ring) / 64x192
+                                      * (four-deep) tiles - what small-M GEMMs (the Temporal Transformer's 1920 rows into
+                                      * N = 768, the 480 query rows) take by default, HERO_WS_SMALL_M=0 turns that off;
+                                      * -1 heuristic (fp32 GEMMs with M <= 32 then run a skinny VALU kernel) */
 int hero_prof_enable(int on);
 int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches);
 

@@ -196,6 +196,27 @@ def test_synth_batch_contract():
             row += 1
 
 
+def test_grad_exchange_backend_selection(monkeypatch):
+    """HERO_COMM=1 selects the C-ABI exchange for CUDA arenas only: a CPU arena (the gloo tests) stays on the process group,
+    host tensors never take the `hero_comm_*` path, and an unknown backend is an error."""
+    import pytest
+    import torch
+    from hero_amd.utils import distributed as D
+    from hero_amd import functional as HF
+    ps = [torch.nn.Parameter(torch.randn(8, 4))]
+    try:
+        monkeypatch.setenv("HERO_COMM", "1")
+        assert D.GradArena(ps, install=False).backend == "torch"
+        assert not D._abi_on(torch.zeros(4))
+        monkeypatch.delenv("HERO_COMM")
+        assert D.GradArena(ps, install=False).backend == "torch"
+        assert D.GradArena(ps, install=False, backend="abi").backend == "abi"       # explicit choice: honoured (needs a GPU to run)
+        with pytest.raises(ValueError):
+            D.GradArena(ps, install=False, backend="mpi")
+    finally:
+        HF.set_grad_sink(None)
+
+
 def test_grad_arena_groups_are_contiguous():
     """GradArena(groups=...) lays the grouped parameters back to back (in group order) wherever the
     first member falls, keeps 16-byte alignment, and dst_group() returns one stacked view of them."""

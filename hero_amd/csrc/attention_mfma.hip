@@ -55,7 +55,10 @@ template <int NB, int WPB, int CLS>
 __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const int pair = blockIdx.x * WPB + wave;
+  // The pair index is uniform across the wave - readfirstlane says so to the compiler: the sequence bounds (and the dropout
+  // seed below) become SCALAR loads issued together, instead of two vector loads each followed by its own s_waitcnt vmcnt(0)
+  // in front of every other load of the wave (and a third serial round trip for the seed behind the first MFMAs).
+  const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (pair >= a.S * a.H) return;                       // wave-uniform; no workgroup barriers below
   const int s = pair / a.H, h = pair - s * a.H, D = a.H * 64, ld = 3 * D;
   // packed batches: rows [seq_off[s], seq_off[s+1]); a.L (the maximum) stays the stride of probs / dropout indices
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
   if (L <= 0) return;
   if ((CLS == 1 && L > 32) || (CLS == 2 && L <= 32)) return;      // wave-uniform: the other launch owns this sequence
+  DropCtx drop(a.dropout);
   bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (32 * NB * RS);
   const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
   const bf16_t* kp = qp + D;
@@ -115,7 +119,6 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
         vf[dt][jt][ks] = tr_frag(tr_addr(Vs, RS * 2, r0, dt, lane), tr_addr(Vs, RS * 2, r0 + 8, dt, lane));
       }
 
-  DropCtx drop(a.dropout);
   f32x16_t cx[2][NB];
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   constexpr int PS = R + 8;                              // [query][key] bf16 row stride (elements)
   constexpr int WAVE_BYTES = 3 * R * RS * 2 + 2 * R * PS * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const int pair = blockIdx.x * WPB + wave;
+  const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);      // uniform: scalar loads (see the forward kernel)
   if (pair >= a.S * a.H) return;
   const int s = pair / a.H, h = pair - s * a.H, D = a.H * 64, ld = 3 * D;
   const int Lm = a.L, Lp = (Lm + 3) & ~3;
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
   if (L <= 0) return;
   if ((CLS == 1 && L > 32) || (CLS == 2 && L <= 32)) return;      // wave-uniform: the other launch owns this sequence
+  DropCtx drop(a.dropout);
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + wave * WAVE_BYTES);
   bf16_t* Qs = Ks + R * RS;
   bf16_t* Os = Qs + R * RS;
@@ -278,7 +282,6 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
         kf[dt][jt][ks] = tr_frag(tr_addr(Ks, RS * 2, r0, dt, lane), tr_addr(Ks, RS * 2, r0 + 8, dt, lane));
       }
 
-  DropCtx drop(a.dropout);
   bf16_t* dq = static_cast<bf16_t*>(a.dqkv) + (size_t)row0 * ld + h * 64;
   f32x16_t gq[2][NB];
 #pragma unroll

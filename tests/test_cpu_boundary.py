@@ -481,3 +481,36 @@ def test_hero_comm_boundary_without_a_gpu(built_lib):
         assert L.hero_comm_unique_id(uid) == 0 and any(uid.raw)
         h = C.c_void_p()
         assert L.hero_comm_init(uid, 2, 2, C.byref(h)) != 0 and b"bad arguments" in L.hero_last_error()
+
+
+def test_pack_plan_row_maps_are_consistent():
+    """BertEncoder._pack_plan (host logic of the ragged path, model/layers.py:299-302 semantics): the padded -> packed and
+    packed -> padded row maps of several sequence groups are inverse to each other, sequences stay contiguous and in order,
+    and (almost) dense batches / sequences beyond the variable-length kernels' limit get no plan."""
+    import torch
+    from hero_amd.model.layers import BertEncoder
+    g = torch.Generator().manual_seed(5)
+    lens_a = torch.randint(3, 25, (7,), generator=g)
+    lens_b = torch.randint(1, 16, (4,), generator=g)
+    ma = (torch.arange(24)[None, :] < lens_a[:, None]).long()
+    mb = (torch.arange(15)[None, :] < lens_b[:, None]).long()
+    plan = BertEncoder._pack_plan([ma, mb], [7 * 24, 4 * 15], max_len=64)
+    assert plan is not None
+    gather, inverse, inv, back, off, n_seq, lmax = plan
+    valid = int(ma.sum() + mb.sum())
+    assert gather.numel() == valid and n_seq == 11 and lmax == int(max(lens_a.max(), lens_b.max()))
+    flat = torch.cat([ma.reshape(-1), mb.reshape(-1)])
+    assert torch.equal(flat[gather.long()], torch.ones(valid, dtype=flat.dtype))            # only valid positions are packed
+    assert torch.equal(inverse[gather.long()].long(), torch.arange(valid))                 # padded -> packed undoes packed -> padded
+    assert int((inverse < 0).sum()) == flat.numel() - valid
+    assert torch.equal(off.long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.cat([lens_a, lens_b]).cumsum(0)]))
+    assert torch.equal(torch.sort(gather).values, gather)                                   # sequences stay in order, rows contiguous
+    # per group: inv = this group's slice of `inverse`; back = packed row -> row inside the group or -1
+    assert torch.equal(inv[0], inverse[:7 * 24]) and torch.equal(inv[1], inverse[7 * 24:])
+    for gi, (r0, n) in enumerate(((0, 7 * 24), (7 * 24, 4 * 15))):
+        own = (gather >= r0) & (gather < r0 + n)
+        assert torch.equal(back[gi][own].long(), gather[own].long() - r0) and bool((back[gi][~own] == -1).all())
+    # dense batch: nothing to gain; too long for the packed attention kernels: no plan either
+    assert BertEncoder._pack_plan([torch.ones(4, 10, dtype=torch.long)], [40], max_len=64) is None
+    long_mask = (torch.arange(100)[None, :] < torch.tensor([100, 3, 3, 3])[:, None]).long()
+    assert BertEncoder._pack_plan([long_mask], [400], max_len=64) is None

@@ -310,6 +310,37 @@ def feed_run(device, rank, steps, warmup, n_batches=4):
                      "PCIe, copy stream one step ahead)" % n_batches}
 
 
+def launch_command(n, argv, n_devices, port=None):
+    """The command (and extra environment) `python bench.py --gpus N` turns itself into when N > 1 and no launcher has
+    set WORLD_SIZE: one process per GPU under torch.distributed.run on 127.0.0.1, exactly what the driver's own N > 1
+    command line is.  On a box with fewer than N GPUs the ranks share device 0 and talk over gloo (RCCL refuses two
+    ranks on one device): a PLUMBING run - process group, broadcast, bucketed exchange, negatives, max-over-ranks
+    timing, the one JSON line - that says so in `config.parallelism`."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = {"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    if n_devices < n:
+        env["HERO_BENCH_ONE_DEVICE"] = "1"
+        env["HERO_BENCH_BACKEND"] = os.environ.get("HERO_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return cmd, env
+
+
+def self_launch(args):
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no GPU visible (the hot path has no CPU fallback)")
+    cmd, env = launch_command(args.gpus, sys.argv[1:], n_dev)
+    sys.stdout.flush()
+    os.execve(cmd[0], cmd, dict(os.environ, **env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,15 +361,19 @@ def main():
                     help="D2: rotate this many DISTINCT pinned host batches through hero_amd.loader.StaticBatchFeeder (H2D of "
                          "the frame features on a copy stream one step ahead, index tensors rebuilt on the device) instead of "
                          "re-running one HBM-resident batch; the headline value is the resident one (0)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "abi"],
+                    help="N > 1: what carries the device collectives - torch.distributed's process group (default, DESIGN 6) or "
+                         "hero_comm_* of the C ABI (RCCL on a side stream of this process)")
     args = ap.parse_args()
 
+    self_launch(args)                                # plain `python bench.py --gpus N`, N > 1: becomes the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if os.environ.get("HERO_BENCH_ONE_DEVICE"):      # plumbing check of the N>1 path on a 1-GPU box
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    one_device = bool(os.environ.get("HERO_BENCH_ONE_DEVICE"))      # plumbing run of the N > 1 path on a box with fewer GPUs
+    if one_device:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -356,6 +391,9 @@ def main():
     from hero_amd.step import TrainStep
     from hero_amd.synth import SHAPES, make_batch
     hero_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    if dist_on and args.exchange == "abi":
+        from hero_amd.utils import distributed as D_
+        D_.set_exchange("abi")                       # collective: the RCCL communicator of hero_comm_* is created here
     if args.workload != "D2":
         out = secondary_workload(args, device, world, rank)
         if rank == 0:
@@ -535,7 +573,9 @@ def main():
             "config": {"workload": "configs[1]: HERO-base TVR finetune micro-step (train-tvr-8gpu.json shapes: "
                                    "32 videos x 60 frames, 15 subs x (4 frames + 20 tokens), 15-token query; "
                                    "vfeat 4352; fwd + VSM loss + bwd, all-reduce/clip/AdamW every 2nd micro-step)",
-                       "global_batch": sh["videos"] * world, "parallelism": "dp%d" % world,
+                       "global_batch": sh["videos"] * world,
+                       "parallelism": "dp%d" % world + (" (PLUMBING run: the %d ranks share ONE device, %s transport - not a scaling "
+                                                        "number)" % (world, torch.distributed.get_backend()) if one_device and world > 1 else ""),
                        "dropout": 0.1, "grad_accum": 2, "launch": launch_mode,
                        "input": ("%d distinct pinned host batches rotated through StaticBatchFeeder (33 MB of frame features per "
                                  "micro-step over PCIe on a copy stream, one step ahead; index tensors rebuilt on the device)" % args.feed)

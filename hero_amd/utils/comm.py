@@ -1,6 +1,6 @@
 """Host side of `hero_comm_*` (include/hero_hip.h): the gradient exchange over RCCL behind the C ABI.
 
-Opt-in (`HERO_COMM=1`, or `GradArena(backend="abi")`); the default exchange goes through torch.distributed's
+Opt-in (`hero_amd.utils.distributed.set_exchange("abi")`, `bench.py --exchange abi`); the default exchange goes through torch.distributed's
 process group (hero_amd/utils/distributed.py).  What the ABI path changes: every collective is enqueued on a HIP stream
 this module owns - no process-group stream, no watchdog thread, no Work objects - so a bucket's all-reduce is an
 ordinary node of the stream (or of the hipGraph being captured on it).  The 128-byte RCCL unique id travels from rank 0
@@ -23,7 +23,7 @@ class Communicator:
         lib = L.lib()
         if not lib.hero_comm_available():
             raise RuntimeError("hero_amd.utils.comm: librccl.so could not be opened; the ABI exchange has no fallback "
-                               "(unset HERO_COMM to use torch.distributed)")
+                               "(set_exchange('torch') uses torch.distributed's process group)")
         on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank() if on else 0
         self.world = dist.get_world_size() if on else 1

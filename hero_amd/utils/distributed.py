@@ -31,9 +31,31 @@ def rank():
     return dist.get_rank() if _on() else 0
 
 
+# Which implementation carries the DEVICE collectives of this process (gradient buckets, parameter broadcast, the
+# forward all-gather of the negatives).  "torch" (default): torch.distributed's process group - the path every multi-rank
+# test covers (two ranks over gloo on CPU and on the GPU box, one rank over RCCL).  "abi": hero_comm_* of the C ABI
+# (hero_amd/utils/comm.py; RCCL enqueued on ONE side stream this process owns).  One setting per process, chosen by
+# set_exchange() BEFORE the first TrainStep - no environment switch; DESIGN.md section 6 says why "torch" is the default.
+_EXCHANGE = ["torch"]
+
+
+def set_exchange(kind):
+    """Collective on every rank.  "abi" creates the RCCL communicator NOW (outside any stream capture: ncclCommInitRank
+    and the unique-id broadcast are illegal under capture, and a rank-divergent first use would deadlock)."""
+    if kind not in ("torch", "abi"):
+        raise ValueError("set_exchange: 'torch' or 'abi'")
+    if kind == "abi":
+        from . import comm
+        comm.communicator()
+    _EXCHANGE[0] = kind
+
+
+def exchange():
+    return _EXCHANGE[0]
+
+
 def _abi_on(t):
-    """HERO_COMM=1: device collectives go through hero_comm_* of the C ABI (hero_amd/utils/comm.py)."""
-    return os.environ.get("HERO_COMM") == "1" and t.is_cuda
+    return _EXCHANGE[0] == "abi" and t.is_cuda
 
 
 def collectives_active():
@@ -64,7 +86,10 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
 def _broadcast(t, root):
     if _abi_on(t):
         from . import comm
-        comm.communicator().broadcast(t, root)
+        c = comm.communicator()
+        c.fork()                                   # every collective of the communicator runs on ITS stream, in program order
+        c.broadcast(t, root, stream=c.stream)
+        c.join()
     else:
         dist.broadcast(t, src=root)
 
@@ -162,15 +187,19 @@ class GradArena(HF.GradSink):
         if compress not in (None, "bf16"):
             raise ValueError("GradArena: compress must be None or 'bf16'")
         self._wire = {}
-        # backend: "torch" = torch.distributed's process group (default); "abi" = hero_comm_* of the C ABI (RCCL enqueued
-        # on a side stream this process owns, hero_amd/utils/comm.py) - HERO_COMM=1 selects it for CUDA arenas
+        # backend: "torch" = torch.distributed's process group; "abi" = hero_comm_* of the C ABI (RCCL enqueued on the side
+        # stream this process owns, hero_amd/utils/comm.py); default: the process-wide set_exchange() choice
         if backend is None:
-            backend = "abi" if os.environ.get("HERO_COMM") == "1" and dev.type == "cuda" else "torch"
+            backend = "abi" if _EXCHANGE[0] == "abi" and dev.type == "cuda" else "torch"
         if backend not in ("torch", "abi"):
             raise ValueError("GradArena: backend must be 'torch' or 'abi'")
+        if backend == "abi" and dev.type != "cuda":
+            raise ValueError("GradArena: backend 'abi' (hero_comm_* = RCCL) needs a CUDA arena")
         self.backend = backend
         self._comm = None
         self._abi_open = False
+        if backend == "abi":               # the communicator exists before any backward pass (or capture) needs it
+            self._abi()
         # static_usage: the caller guarantees that every optimiser step touches the same parameters
         # (one task, fixed graph).  Buckets then wait only for the parameters that received a gradient
         # in the previous step, so a bucket that also holds never-used parameters (pooler, lm_head,
@@ -356,7 +385,9 @@ class GradArena(HF.GradSink):
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                c.allreduce_buckets(bufs)                 # one group on the current stream
+                c.fork()
+                c.allreduce_buckets(bufs, stream=c.stream)     # one group on the communicator's stream
+                c.join()
                 e1.record()
                 torch.cuda.synchronize()
                 times.append(e0.elapsed_time(e1))
@@ -391,8 +422,13 @@ class _AllGatherRows(torch.autograd.Function):
         r, n = rank(), world_size()
         ctx.offset, ctx.dim = sum(dims[:r]), tensor.shape[0]
         if _abi_on(tensor):
-            from . import comm                      # no padding, no cat: the ranks' rows land back to back (current stream)
-            return comm.communicator().allgather_var(tensor.contiguous(), dims)
+            from . import comm                      # no padding, no cat: the ranks' rows land back to back
+            c = comm.communicator()
+            send = tensor.contiguous()
+            c.fork()                                # on the communicator's one stream, like the gradient buckets; `send` and the
+            out = c.allgather_var(send, dims, stream=c.stream)      # result are allocated on the CURRENT stream, which the
+            c.join()                                # join orders behind the collective - no record_stream needed
+            return out
         mx = max(dims)
         buf = tensor.new_zeros((mx,) + tuple(tensor.shape[1:]))
         buf[:tensor.shape[0]] = tensor

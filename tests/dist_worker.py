@@ -27,6 +27,9 @@ def main():
     else:
         dist.init_process_group(backend)
     import hero_amd
+    if len(sys.argv) > 4 and sys.argv[4] == "abi":     # gradient buckets / broadcast / negatives through hero_comm_* (C ABI)
+        from hero_amd.utils import distributed as D_
+        D_.set_exchange("abi")
     from hero_amd.step import TrainStep
     from hero_amd.synth import make_batch
     from hero_amd.utils.misc import set_dropout

@@ -196,24 +196,30 @@ def test_synth_batch_contract():
             row += 1
 
 
-def test_grad_exchange_backend_selection(monkeypatch):
-    """HERO_COMM=1 selects the C-ABI exchange for CUDA arenas only: a CPU arena (the gloo tests) stays on the process group,
-    host tensors never take the `hero_comm_*` path, and an unknown backend is an error."""
+def test_grad_exchange_backend_selection():
+    """The exchange is chosen in code (`set_exchange`, `GradArena(backend=...)`), never by the environment: a CPU arena (the
+    gloo tests) is always on the process group, host tensors never take the `hero_comm_*` path, the C-ABI exchange needs a
+    CUDA arena, and an unknown backend is an error."""
     import pytest
     import torch
     from hero_amd.utils import distributed as D
     from hero_amd import functional as HF
     ps = [torch.nn.Parameter(torch.randn(8, 4))]
     try:
-        monkeypatch.setenv("HERO_COMM", "1")
+        assert D.exchange() == "torch"
         assert D.GradArena(ps, install=False).backend == "torch"
         assert not D._abi_on(torch.zeros(4))
-        monkeypatch.delenv("HERO_COMM")
-        assert D.GradArena(ps, install=False).backend == "torch"
-        assert D.GradArena(ps, install=False, backend="abi").backend == "abi"       # explicit choice: honoured (needs a GPU to run)
+        D._EXCHANGE[0] = "abi"                      # what set_exchange("abi") leaves behind (it also opens RCCL: needs a GPU)
+        assert D.GradArena(ps, install=False).backend == "torch" and not D._abi_on(torch.zeros(4))
+        D._EXCHANGE[0] = "torch"
+        with pytest.raises(ValueError):
+            D.GradArena(ps, install=False, backend="abi")
         with pytest.raises(ValueError):
             D.GradArena(ps, install=False, backend="mpi")
+        with pytest.raises(ValueError):
+            D.set_exchange("horovod")
     finally:
+        D._EXCHANGE[0] = "torch"
         HF.set_grad_sink(None)
 
 

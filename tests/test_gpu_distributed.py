@@ -179,13 +179,13 @@ def test_hero_comm_abi_collectives_one_rank_eager_and_captured():
 
 @pytest.mark.parametrize("wire", ["none", "bf16"])
 def test_one_rank_gradient_exchange_through_the_c_abi(tmp_path, wire):
-    """HERO_COMM=1: the gradient buckets of the data-parallel step travel through hero_comm_allreduce_buckets on the
+    """`set_exchange("abi")`: the gradient buckets of the data-parallel step travel through hero_comm_allreduce_buckets on the
     communicator's side stream (forked at the bucket's finality point, joined in finish()) instead of the process group;
     the worker checks bucketed all-reduce == sum of the local gradients and that optimiser steps stay finite."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1", HERO_COMM="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
            "--master-addr", "127.0.0.1", "--master-port", "29561",
-           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), wire, "nccl"]
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), wire, "nccl", "abi"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.load(open(tmp_path / "rank0.json"))
@@ -193,13 +193,13 @@ def test_one_rank_gradient_exchange_through_the_c_abi(tmp_path, wire):
 
 
 def test_bench_one_rank_exchange_through_the_c_abi_captured_in_a_hipgraph():
-    """bench.py with HERO_COMM=1: eager run, then the step captured WITH its hero_comm all-reduces; the comm block names
+    """`bench.py --exchange abi`: eager run, then the step captured WITH its hero_comm all-reduces; the comm block names
     the exchange."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1", HERO_COMM="1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HERO_DP_FORCE_COLLECTIVES="1",
                HERO_DP_GRAPH="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
            "--master-addr", "127.0.0.1", "--master-port", "29563", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline"]
+           "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--exchange", "abi"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -11,12 +11,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HERO_HIP_LIB") or os.path.join(_HERE, "libhero_hip.so")   # HERO_HIP_LIB: alternative build (A/B runs)
 
+ABI_VERSION = 2          # include/hero_hip.h HERO_ABI_VERSION this binding's struct layouts were written against
 F32, BF16 = 0, 1
 LAYOUT_K, LAYOUT_O = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DG, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
+    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
@@ -38,7 +39,7 @@ class Dropout(C.Structure):
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
                 ("act", C.c_int), ("out_f32", C.c_int), ("beta", C.c_float),
-                ("split_k", C.c_int), ("dropout", Dropout), ("colsum", C.c_void_p)]
+                ("split_k", C.c_int), ("dropout", Dropout), ("colsum", C.c_void_p), ("split_stride", C.c_longlong)]
 
 
 class CrossEntropy(C.Structure):
@@ -173,6 +174,10 @@ def lib():
                 "path." % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.hero_last_error.restype = C.c_char_p
+        have = L.hero_abi_version()
+        if have != ABI_VERSION:
+            raise RuntimeError("hero_amd: %s reports ABI version %d, this binding was written against %d (struct layouts "
+                               "differ: rebuild with `python -m hero_amd.build --force`)" % (LIB_PATH, have, ABI_VERSION))
         L.hero_layernorm_bwd_workspace_bytes.restype = C.c_size_t
         L.hero_colsum_workspace_bytes.restype = C.c_size_t
         L.hero_colsum_multi_workspace_bytes.restype = C.c_size_t
@@ -181,6 +186,8 @@ def lib():
         L.hero_layernorm_bwd_blocks.argtypes = [C.c_int]
         L.hero_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [
             C.POINTER(GemmEpilogue), C.c_void_p]
+        L.hero_gemm_splits.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.hero_fold_slabs.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.hero_wgrad_group.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hero_wgrad_batch_plan.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.hero_wgrad_batch.argtypes = [C.POINTER(WgradProblem), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]

@@ -494,13 +494,12 @@ static size_t small_bwd_lds(int L) { const int Lp = (L + 3) & ~3; return ((size_
 template <typename T, int LPK>
 static int launch_small(const HeroAttn& a, bool bwd, hipStream_t s) {
   const size_t lds = bwd ? small_bwd_lds(a.L) : small_fwd_lds(a.L);
+  HERO_REQUIRE(lds <= 150 * 1024, "hero_attention(small): L = %d needs %zu bytes of LDS", a.L, lds);
   if (bwd) {
-    static size_t cap = 65536;
-    if (lds > cap) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_small_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cap = lds; }
+    HERO_ENSURE_LDS((&attn_bwd_small_kernel<T, LPK>), 150 * 1024, "attn_bwd_small_kernel");
     hipLaunchKernelGGL((attn_bwd_small_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
   } else {
-    static size_t cap = 65536;
-    if (lds > cap) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_small_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cap = lds; }
+    HERO_ENSURE_LDS((&attn_fwd_small_kernel<T, LPK>), 150 * 1024, "attn_fwd_small_kernel");
     hipLaunchKernelGGL((attn_fwd_small_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
   }
   return check_launch(bwd ? "hero_attention_bwd(small)" : "hero_attention_fwd(small)");
@@ -528,11 +527,8 @@ template <typename T> static int max_len(int backward) {
 template <typename T, int LPK>
 static int launch_fwd(const HeroAttn& a, hipStream_t s) {
   const size_t lds = fwd_lds<T>(a.L);
-  static size_t attr = 65536;   // raise the dynamic-LDS cap only when (and as far as) needed
-  if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, LPK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
+  HERO_REQUIRE(lds <= LDS_BUDGET, "hero_attention_fwd: L = %d needs %zu bytes of LDS", a.L, lds);
+  HERO_ENSURE_LDS((&attn_fwd_kernel<T, LPK>), LDS_BUDGET, "attn_fwd_kernel");
   hipLaunchKernelGGL((attn_fwd_kernel<T, LPK>), dim3(a.S * a.H), dim3(256), lds, s, a);
   return check_launch("hero_attention_fwd");
 }
@@ -546,11 +542,8 @@ static int launch_bwd(const HeroAttn& a, hipStream_t s) {
   R &= ~3;
   if (R < 4) R = a.L < 4 ? a.L : 4;
   const size_t lds = fixed + (size_t)2 * R * Lp * sizeof(float);
-  static size_t attr = 65536;
-  if (lds > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, LPK, KPW, QO_GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
+  HERO_REQUIRE(lds <= LDS_BUDGET, "hero_attention_bwd: L = %d needs %zu bytes of LDS", a.L, lds);
+  HERO_ENSURE_LDS((&attn_bwd_kernel<T, LPK, KPW, QO_GLOBAL>), LDS_BUDGET, "attn_bwd_kernel");
   hipLaunchKernelGGL((attn_bwd_kernel<T, LPK, KPW, QO_GLOBAL>), dim3(a.S * a.H), dim3(256), lds, s, a, R);
   return check_launch("hero_attention_bwd");
 }
@@ -564,16 +557,11 @@ static int bwd_by_len(const HeroAttn& a, hipStream_t s) {
 int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s);        // attention_mfma.hip (bf16, L <= 64)
 int attn_mfma_long_run(const HeroAttn& a, bool bwd, hipStream_t s);   // attention_mfma_long.hip (bf16, 64 < L <= 256)
 
-static bool use_mfma() {   // tuning hook: HERO_ATTN_MFMA=0 keeps the fp32-VALU kernels for bf16 too
-  static const bool on = [] { const char* e = getenv("HERO_ATTN_MFMA"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 template <typename T>
 static int run(const HeroAttn& a, bool bwd, hipStream_t s) {
-  if (sizeof(T) == 2 && a.L <= 64 && use_mfma()) return attn_mfma_run(a, bwd, s);
+  if (sizeof(T) == 2 && a.L <= 64) return attn_mfma_run(a, bwd, s);
   // longer sequences on the matrix cores too; the backward takes delta_i = dO_i . ctx_i from the forward output
-  if (sizeof(T) == 2 && a.L <= 256 && use_mfma() && (!bwd || a.ctx)) return attn_mfma_long_run(a, bwd, s);
+  if (sizeof(T) == 2 && a.L <= 256 && (!bwd || a.ctx)) return attn_mfma_long_run(a, bwd, s);
   if (a.seq_off && a.L > 64) {
     set_error("hero_attention_%s: packed batches with L = %d > 64 need the bf16 matrix-core kernels (and ctx in the backward)",
               bwd ? "bwd" : "fwd", a.L);
@@ -625,9 +613,9 @@ extern "C" int hero_attention_bwd(const HeroAttn* a, hero_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   return a->dtype == HERO_BF16 ? run<bf16_t>(*a, true, s) : run<float>(*a, true, s);
 }
-extern "C" int hero_attention_stats_ok(int dtype, int L) { return dtype == HERO_BF16 && L >= 1 && L <= 64 && use_mfma() ? 1 : 0; }
-extern "C" int hero_attention_max_packed_len(int dtype) { return dtype == HERO_BF16 && use_mfma() ? 256 : 64; }
+extern "C" int hero_attention_stats_ok(int dtype, int L) { return dtype == HERO_BF16 && L >= 1 && L <= 64 ? 1 : 0; }
+extern "C" int hero_attention_max_packed_len(int dtype) { return dtype == HERO_BF16 ? 256 : 64; }
 extern "C" int hero_attention_max_len(int dtype, int backward) {
-  if (dtype == HERO_BF16 && use_mfma()) return 256;       // matrix-core kernels (the backward wants a.ctx beyond 64)
+  if (dtype == HERO_BF16) return 256;       // matrix-core kernels (the backward wants a.ctx beyond 64)
   return dtype == HERO_BF16 ? max_len<bf16_t>(backward) : max_len<float>(backward);
 }

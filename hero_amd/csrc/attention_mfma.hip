@@ -412,11 +412,9 @@ int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
   const int grid = (pairs + WPB - 1) / WPB;
   if (bwd) {
     const size_t lds = (size_t)WPB * (3 * R * RS * 2 + 2 * R * (R + 8) * 2);
-    static bool set = false;
-    if (!set && lds > 65536) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, false, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kernel<NB, WPB, true, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      set = true;
+    if (lds > 65536) {
+      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, false, CLS>), lds, "attn_mfma_bwd_kernel");
+      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, true, CLS>), lds, "attn_mfma_bwd_kernel");
     }
     if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
     else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);

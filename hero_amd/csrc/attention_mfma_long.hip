@@ -337,23 +337,16 @@ __global__ __launch_bounds__(64 * NB) void attn_long_bwd_dkv_kernel(HeroAttn a) 
   store_tileT(dq + 2 * c.D, c.ld, c.L, jt, gv, lane);
 }
 
-template <typename F>
-void set_lds(F* fn, size_t lds) {
-  if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
 template <int NB>
 int launch_long(const HeroAttn& a, bool bwd, hipStream_t s) {
   const int grid = a.S * a.H;
   const size_t tiles = (size_t)2 * 32 * NB * RS * 2;
-  static bool set = false;
   const size_t lds_kv = tiles + 32 * NB * 4 + (size_t)NB * 2 * 32 * 40 * 2;
-  if (!set) {
-    set_lds(&attn_long_fwd_kernel<NB>, tiles);
-    set_lds(&attn_long_bwd_dq_kernel<NB>, tiles);
-    set_lds(&attn_long_bwd_dkv_kernel<NB>, lds_kv);
-    set = true;
+  if (tiles > 65536) {
+    HERO_ENSURE_LDS((&attn_long_fwd_kernel<NB>), tiles, "attn_long_fwd_kernel");
+    HERO_ENSURE_LDS((&attn_long_bwd_dq_kernel<NB>), tiles, "attn_long_bwd_dq_kernel");
   }
+  if (lds_kv > 65536) HERO_ENSURE_LDS((&attn_long_bwd_dkv_kernel<NB>), lds_kv, "attn_long_bwd_dkv_kernel");
   if (!bwd) {
     hipLaunchKernelGGL((attn_long_fwd_kernel<NB>), dim3(grid), dim3(64 * NB), tiles, s, a);
     return check_launch("hero_attention_fwd(mfma, long)");

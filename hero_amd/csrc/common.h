@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/hero_hip.h"
 
 namespace hero {
@@ -193,6 +194,17 @@ template <> __device__ __forceinline__ void gelu_both<bf16_t>(float x, float& y,
 // error plumbing (api.cpp)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// "This kernel may use `bytes` of dynamic LDS": hipFuncSetAttribute is a PER-DEVICE setting and can be refused, so it is
+// applied once per (kernel, device) - a bit per device ordinal in the call site's own atomic mask, thread-safe - and its
+// result is checked (the results were discarded behind process-wide `static bool` flags).
+int ensure_dyn_lds(const void* fn, int bytes, std::atomic<uint64_t>& done, const char* what);
+#define HERO_ENSURE_LDS(fnptr, bytes, what)                                                                     \
+  do {                                                                                                          \
+    static std::atomic<uint64_t> lds_ok_{0};                                                                    \
+    const int lds_rc_ = ::hero::ensure_dyn_lds(reinterpret_cast<const void*>(fnptr), (int)(bytes), lds_ok_, (what)); \
+    if (lds_rc_ != HERO_OK) return lds_rc_;                                                                     \
+  } while (0)
 
 #define HERO_REQUIRE(cond, ...)        \
   do {                                 \

@@ -251,13 +251,15 @@ struct GemmArgs {
 
 template <typename T, typename CF, int EK>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)[CF::TM][CF::TN], char* smem, int m0, int n0,
-                                              int arow0, int brow0, int lane) {
+                                              int arow0, int brow0, int lane, int kbeg = 0) {
   constexpr int BM = CF::BM, BN = CF::BN, NT = CF::NT, TM = CF::TM, TN = CF::TN;
   constexpr bool GEN = (EK & EK_GENERIC) != 0;
   const HeroGemmEpilogue& e = g.epi;
-  // ---- split-K: fp32 atomics straight from the accumulator layout
+  // ---- split-K: fp32 straight from the accumulator layout - atomics into C, or (split_stride != 0) plain stores into
+  // this split's own slab C + split * split_stride, folded afterwards in slab order (hero_fold_slabs): bit-reproducible
   if (GEN && e.split_k > 1) {
-    float* C = static_cast<float*>(g.C);
+    const bool slab = e.split_stride != 0;
+    float* C = static_cast<float*>(g.C) + (slab ? (size_t)(kbeg / g.k_per_split) * (size_t)e.split_stride : (size_t)0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -266,7 +268,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int gm = m0 + arow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (gm < g.M && gn < g.N) atomicAdd(C + (size_t)gm * g.ldc + gn, acc[i][j][r]);
+          if (gm < g.M && gn < g.N) {
+            if (slab) C[(size_t)gm * g.ldc + gn] = acc[i][j][r];
+            else atomicAdd(C + (size_t)gm * g.ldc + gn, acc[i][j][r]);
+          }
         }
       }
     return;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) 
     wait_stages(min(NSG - 2, nk - 2 - kt));          // tile kt + 1 landed
     __syncthreads();                                 // ... and everyone is done with cur
   }
-  gemm_epilogue<T, CF, EK>(g, acc, smem, m0, n0, arow0, brow0, lane);
+  gemm_epilogue<T, CF, EK>(g, acc, smem, m0, n0, arow0, brow0, lane, tc.kbeg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       __syncthreads();
     }
   }
-  gemm_epilogue<bf16_t, CF, EK_GENERIC>(g, acc, smem, m0, n0, arow0, brow0, lane);
+  gemm_epilogue<bf16_t, CF, EK_GENERIC>(g, acc, smem, m0, n0, arow0, brow0, lane, tc.kbeg);
 }
 
 template <typename T, int ALAY, int BLAY, typename CF>
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(CF::NT) __attribute__((amdgpu_waves_per_eu(1, 2))) 
     __syncthreads();
   }
 
-  gemm_epilogue<T, CF, EK_GENERIC>(g, acc, smem, m0, n0, arow0, brow0, lane);
+  gemm_epilogue<T, CF, EK_GENERIC>(g, acc, smem, m0, n0, arow0, brow0, lane, kbeg);
 }
 
 // out <- beta * out over an [M, N] fp32 matrix (pre-pass of the split-K atomics path)
@@ -822,11 +827,7 @@ typedef Cfg<2, 2, 1, 1> Cfg64;     // 64x64 tiles for problems that leave most C
 
 template <typename T, int AL, int BL, typename CF>
 static int launch(GemmArgs g, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AL, BL, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS);
-    attr_set = true;
-  }
+  HERO_ENSURE_LDS((&gemm_kernel<T, AL, BL, CF>), CF::LDS, "gemm_kernel");
   g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
   g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
   const int split = g.epi.split_k > 1 ? g.epi.split_k : 1;
@@ -891,11 +892,7 @@ template __global__ void gemm_glds_kernel<float, Cfg256, EK_GENERIC>(GemmArgs);
 
 template <typename T, typename CF, int EK>
 static int launch_glds_ek(GemmArgs g, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<T, CF, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, GldsRing<CF>::LDS);
-    attr_set = true;
-  }
+  HERO_ENSURE_LDS((&gemm_glds_kernel<T, CF, EK>), GldsRing<CF>::LDS, "gemm_glds_kernel");
   g.tiles_m = (g.M + CF::BM - 1) / CF::BM;
   g.tiles_n = (g.N + CF::BN - 1) / CF::BN;
   const int split = g.epi.split_k > 1 ? g.epi.split_k : 1;
@@ -953,11 +950,7 @@ static int launch_glds_tr(GemmArgs g, hipStream_t s) {
       ps = nullptr;
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
-  }
+  HERO_ENSURE_LDS(&gemm_glds_tr_kernel, 65536, "gemm_glds_tr_kernel");
   hipLaunchKernelGGL(gemm_glds_tr_kernel, dim3(grid), dim3(256), 65536, s, g);
   if (ps) {
     (void)hipEventRecord(e1, s);
@@ -1129,6 +1122,8 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
                  epi->act == HERO_ACT_MUL_AUX) || epi->aux,
                "hero_gemm: activation %d needs aux", epi->act);
   HERO_REQUIRE(!epi->colsum || (epi->split_k <= 1 && !epi->out_f32), "hero_gemm: epilogue.colsum excludes split_k / out_f32");
+  HERO_REQUIRE(epi->split_stride == 0 || (epi->split_k > 1 && epi->split_stride >= (long long)(M - 1) * ldc + N),
+               "hero_gemm: split_stride needs split_k > 1 and slabs that hold [M, ldc]");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -1144,11 +1139,7 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
       !epi->out_f32 && epi->split_k <= 1 && epi->dropout.threshold16 == 0) {
     void* tok = gemm_prof_begin(3, s);
     const int lds = 32 * (K < 1024 ? K : 1024) * 4 + 16;       // + the dummy slot of the copy
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1024 * 4 + 16);
-      attr_set = true;
-    }
+    HERO_ENSURE_LDS(&gemm_skinny_f32_kernel, 32 * 1024 * 4 + 16, "gemm_skinny_f32_kernel");
     hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3((N + 7) / 8), dim3(256), lds, s, static_cast<const float*>(A), static_cast<const float*>(B),
                        static_cast<float*>(C), epi->bias, M, N, K, lda, ldb, ldc);
     gemm_prof_end(tok, 2.0 * (double)M * (double)N * (double)K, s);
@@ -1167,7 +1158,7 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
       const int per = (ktiles + split - 1) / split;
       split = (ktiles + per - 1) / per;
       if (split > 1) {
-        if (epi->beta != 1.f) {  // atomics accumulate into beta * C
+        if (epi->split_stride == 0 && epi->beta != 1.f) {  // atomics accumulate into beta * C (slabs are overwritten)
           hipLaunchKernelGGL(scale_f32_kernel, dim3(1024), dim3(256), 0, s, static_cast<float*>(C), M, N, ldc, epi->beta);
           const int rc = check_launch("hero_gemm(scale)");
           if (rc) return rc;
@@ -1185,9 +1176,18 @@ extern "C" int hero_gemm(const void* A, const void* B, void* C, int M, int N, in
   return dtype == HERO_BF16 ? dispatch<bf16_t>(g, a_layout, b_layout, cfg, s) : dispatch<float>(g, a_layout, b_layout, cfg, s);
 }
 
+extern "C" int hero_gemm_splits(int K, int split_k, int dtype) {
+  const int bk = dtype == HERO_BF16 ? 64 : 32;
+  const int ktiles = (K + bk - 1) / bk;
+  int split = split_k < ktiles ? split_k : ktiles;
+  if (split <= 1) return 1;
+  const int per = (ktiles + split - 1) / split;
+  return (ktiles + per - 1) / per;
+}
+
 // Tuning hook: force a tile geometry (0: 128x128, 1: 192x128, 2: 256x256, 3: 64x64 [1 and 3: direct-to-LDS path only], -1: heuristic).
 extern "C" int hero_gemm_force_config(int cfg) {
-  if (cfg >= 8 && cfg <= 14) {     // 13 / 14: the 64 x 128 / 64 x 192 wave-specialised geometries (small-M, long-K GEMMs)     // wave-specialised kernels never / always 192 x 192 / always 128 x 192 (4-wave heuristic otherwise); 11 / 12: the latter two with the deferred epilogue
+  if (cfg >= 8 && cfg <= 14 && cfg != 11 && cfg != 12) {     // wave-specialised kernels: 8 never, 9 / 10 always 192 x 192 / 128 x 192, 13 / 14 the 64 x 128 / 64 x 192 geometries (small-M, long-K GEMMs)
     g_force_cfg = cfg;
     g_use_glds = 1;
     g_group = 0;

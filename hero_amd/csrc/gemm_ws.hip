@@ -908,7 +908,6 @@ static int num_cus() {
   static int n = [] {
     int dev = 0, v = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    if (const char* e = getenv("HERO_WS_LAB_CUS")) { const int c = atoi(e); if (c >= 8 && c <= v) v = c; }   // lab: tools/lab/two_halves.py
     return v > 0 ? v : 256;
   }();
   return n;
@@ -917,11 +916,7 @@ static int num_cus() {
 template <int TM, int TN, bool TR, int EK>
 static int launch(WsArgs g, int slot, hipStream_t s) {
   typedef Geo<TM, TN> G;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws_kernel<TM, TN, TR, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    attr_set = true;
-  }
+  HERO_ENSURE_LDS((&gemm_ws_kernel<TM, TN, TR, EK>), G::LDS, "gemm_ws_kernel");
   const int grid = g.nwork < num_cus() ? g.nwork : num_cus();
   void* tok = gemm_prof_begin(slot, s);
   hipLaunchKernelGGL((gemm_ws_kernel<TM, TN, TR, EK>), dim3(grid), dim3(512), G::LDS, s, g);
@@ -947,40 +942,18 @@ static int launch_kk(const WsArgs& g, hipStream_t s) {
   return -1;
 }
 
-// gemm_wsd.hip: the same problems on the kernel whose epilogue is drained by the loader waves during the next main loop
-template <int TM, int TN> int launch_kk_deferred(const WsArgs& g, hipStream_t s);
-
-// The deferred epilogue is OFF by default: measured on MI355X (tools/lab/wsd_ab.py, profiles/r04_wsd_ab.txt) it is 1.0-1.3x
-// SLOWER than the in-line one on every epilogue that has arithmetic (bit-equal results).  The loader waves have no slack:
-// they sit in the issue of the 12 DMA pieces of a step for ~1200 of its ~1660 cycles (the L2 -> LDS fill is as critical
-// as the MFMAs), so every VALU instruction and every store they carry delays the ring.  HERO_WS_DEFER=1 / force 11, 12.
-// 64-row geometries for small-M GEMMs with long reductions (HERO_WS_SMALL_M=0: the 4-wave kernels of rounds 1-3)
-static bool small_m_default() {
-  static const bool on = [] { const char* v = getenv("HERO_WS_SMALL_M"); return !(v && v[0] == '0'); }();
-  return on;
-}
-
-static bool defer_default() {
-  static const bool on = [] { const char* v = getenv("HERO_WS_DEFER"); return v && v[0] == '1'; }();
-  return on;
-}
-
 }  // namespace ws
 
 // Problems this family takes: bf16, K,K operands with one of the six hot-path epilogues, or the O,O
 // wgrad accumulate; large enough to fill the chip with 192 x 192 (or, under one round, 128 x 192) tiles.
-// force_cfg: -1 heuristic, 8 never, 9 always 192 x 192, 10 always 128 x 192 (when the shape is legal) - both with the in-line
-// epilogue; 11 / 12: the same two geometries with the deferred epilogue (gemm_wsd.hip).  The heuristic takes the deferred
-// kernel wherever it has the epilogue (everything but gelu' + column sums).
+// force_cfg: -1 heuristic, 8 never, 9 always 192 x 192, 10 always 128 x 192, 13 / 14 always 64 x 128 / 64 x 192 (when the shape
+// is legal).  (Round 4's deferred-epilogue variant - the finished tile parked in the loader waves' registers and drained
+// during the next main loop, bit-exact and 1.0-1.3x SLOWER, profiles/r04_wsd_ab.txt - lives in tools/lab/gemm_wsd.hip.)
 int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_layout,
                 int b_layout, const HeroGemmEpilogue& epi, int force_cfg, hipStream_t s) {
   using namespace ws;
   if (force_cfg == 8) return -1;
-  if ((force_cfg < 9 || force_cfg > 14) && force_cfg != -1) return -1;      // a forced 4-wave geometry
-  const int force_cfg_in = force_cfg;
-  const bool defer = force_cfg == -1 && defer_default();
-  if (force_cfg == 11) force_cfg = 9;
-  if (force_cfg == 12) force_cfg = 10;
+  if ((force_cfg < 9 || force_cfg > 14 || force_cfg == 11 || force_cfg == 12) && force_cfg != -1) return -1;      // a forced 4-wave geometry
   typedef Geo<3, 3> G;
   const bool kk = a_layout == HERO_LAYOUT_K && b_layout == HERO_LAYOUT_K;
   const bool oo = a_layout == HERO_LAYOUT_O && b_layout == HERO_LAYOUT_O;
@@ -1017,7 +990,6 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
     if (small) {
       g.tiles_m = (M + G2::BM - 1) / G2::BM;
       g.nwork = t23;
-      if ((defer && t23 > cus) || force_cfg_in == 12) { const int rc = launch_kk_deferred<2, 3>(g, s); if (rc != -1) return rc; }
       return launch_kk<2, 3>(g, s);
     }
     // Under half a round of 192 x 192 tiles - the Temporal Transformer's 1920 rows into N = 768: 40 tiles - the 64-row
@@ -1025,7 +997,7 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
     // large tiles keep with three stages).  The 4-wave 64 x 64 kernels put 360 workgroups of 16 KB steps on 256 CUs and are
     // bound by the busiest CU's L2 -> LDS fill (two tiles x 48 steps: 26 us at K = 3072, the vendor library 17.7,
     // profiles/r04_vs_library.txt); 18.2 us with this geometry, 6.7 vs 8.0 at K = 768 (tools/lab/smallm_ws.py).
-    if (force_cfg == 13 || force_cfg == 14 || (force_cfg == -1 && small_m_default() && ntile * 2 < cus && K >= 512)) {
+    if (force_cfg == 13 || force_cfg == 14 || (force_cfg == -1 && ntile * 2 < cus && K >= 512)) {
       typedef Geo<1, 2> G12;
       typedef Geo<1, 3> G13;
       const int rows64 = (M + 63) / 64;
@@ -1044,8 +1016,6 @@ int gemm_ws_run(const void* A, const void* B, void* C, int M, int N, int K, int 
     // worth it from about half a round of tiles; below that the 4-wave 64 x 64 / 128 x 128 tiles fill the chip better
     if (force_cfg != 9 && ntile * 2 < cus) return -1;
     g.nwork = ntile;
-    // deferred epilogue where workgroups walk more than one tile (a workgroup's LAST tile has nothing to hide its drain behind)
-    if ((defer && ntile > cus) || force_cfg_in == 11) { const int rc = launch_kk_deferred<3, 3>(g, s); if (rc != -1) return rc; }
     return launch_kk<3, 3>(g, s);
   }
   // O,O: fp32 accumulate, reduction split so that the items fill the CUs
@@ -1115,11 +1085,7 @@ extern "C" int hero_wgrad_group(const HeroWgradProblem* probs, int n, int K, int
   if (ok && (long long)tiles * ksteps >= 8LL * cus) {
     for (int i = n; i < 4; ++i) g.p[i] = g.p[0];
     g.nprob = n; g.K = K; g.ksteps = ksteps; g.total_tiles = tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-      attr_set = true;
-    }
+    HERO_ENSURE_LDS(&gemm_wsg_kernel, G::LDS, "gemm_wsg_kernel");
     double flops = 0.0;
     for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * K;
     void* tok = gemm_prof_begin(9, s);
@@ -1309,11 +1275,7 @@ extern "C" int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int
   if (!flags_of[dev]) HERO_REQUIRE(hipGetSymbolAddress(reinterpret_cast<void**>(&flags_of[dev]), HIP_SYMBOL(hero::ws::g_wsb_flags)) == hipSuccess,
                                    "hero_wgrad_batch: flag storage");
   g.flags = flags_of[dev];
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wsb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    attr_set = true;
-  }
+  HERO_ENSURE_LDS(&gemm_wsb_kernel, G::LDS, "gemm_wsb_kernel");
   void* tok = gemm_prof_begin(9, s);
   hipLaunchKernelGGL(gemm_wsb_kernel, dim3(num_cus()), dim3(512), G::LDS, s, g);
   gemm_prof_end(tok, flops, s);

@@ -620,12 +620,8 @@ extern "C" int hero_segment_sort(const int32_t* idx, int rows, int n_dst, int sk
   int nbits = 1;
   while ((1 << nbits) <= n_dst) ++nbits;              // keys 0 .. n_dst - 1 and the all-ones key of the dropped rows
   nbits = (nbits + 3) & ~3;
-  static bool attr_set = false;
   const int lds = (16 * SORT_NT + 32) * (int)sizeof(uint32_t);
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&segment_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  HERO_ENSURE_LDS(&segment_sort_kernel, lds, "segment_sort_kernel");
   uint2* b0 = static_cast<uint2*>(workspace);
   hipLaunchKernelGGL(segment_sort_kernel, dim3(1), dim3(SORT_NT), lds, static_cast<hipStream_t>(stream), idx, rows,
                      skip_idx >= 0 ? skip_idx : -1, nbits, b0, b0 + rows, order);
@@ -720,6 +716,30 @@ extern "C" int hero_add(const void* a, const void* b, void* y, size_t n, int dty
   else if (dtype == HERO_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
   else { set_error("hero_add: bad dtype %d", dtype); return HERO_ERR_ARG; }
   return check_launch("hero_add");
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(256) fold_slabs_kernel(const float* __restrict__ slabs, int n_slabs, size_t stride, TO* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = *reinterpret_cast<const float4*>(slabs + 4 * i);
+    for (int s = 1; s < n_slabs; ++s) {                        // slab order = summation order: bit-reproducible
+      const float4 b = *reinterpret_cast<const float4*>(slabs + (size_t)s * stride + 4 * i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    V4<TO>::st(out + 4 * i, a);
+  }
+}
+
+extern "C" int hero_fold_slabs(const float* slabs, int n_slabs, size_t stride, void* out, size_t n, int out_dtype, hero_stream_t stream) {
+  HERO_REQUIRE(slabs && out && n_slabs >= 1, "hero_fold_slabs: null pointer / no slab");
+  HERO_REQUIRE(n % 4 == 0 && stride % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 7) == 0, "hero_fold_slabs: n and stride must be multiples of 4, pointers aligned");
+  if (n == 0) return HERO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(n >> 2);
+  if (out_dtype == HERO_F32) hipLaunchKernelGGL(fold_slabs_kernel<float>, dim3(grid), dim3(256), 0, s, slabs, n_slabs, stride, (float*)out, n >> 2);
+  else if (out_dtype == HERO_BF16) hipLaunchKernelGGL(fold_slabs_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, slabs, n_slabs, stride, (bf16_t*)out, n >> 2);
+  else { set_error("hero_fold_slabs: bad dtype %d", out_dtype); return HERO_ERR_ARG; }
+  return check_launch("hero_fold_slabs");
 }
 
 extern "C" int hero_sumsq(const float* g, size_t n, float* sumsq, float* workspace, hero_stream_t stream) {

@@ -290,10 +290,10 @@ def _p(t):
 
 
 def k_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, al, bl, dtype_code, bias=None, residual=None,
-           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None, colsum=None):
+           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None, colsum=None, split_stride=0):
     """A/B/Cm may be tensors or raw device pointers (int) for column-sliced operands."""
     epi = L.GemmEpilogue(_p(bias), _p(residual), _p(aux), act, 1 if out_f32 else 0,
-                         beta, split_k, _d(drop), _p(colsum))
+                         beta, split_k, _d(drop), _p(colsum), split_stride)
     L.check(L.lib().hero_gemm(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, al, bl,
                               dtype_code, C.byref(epi), L.stream()))
 
@@ -324,7 +324,8 @@ def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None, colsum=None):
     M, N = dy2.shape
     K = Wt.shape[0]
     if (dy2.dtype == torch.bfloat16 and act == L.ACT_NONE and aux is None and residual is None and colsum is None
-            and N >= 8192 and M * K <= (1 << 21)):
+            and N >= 8192 and M * K <= (1 << 21) and (M * K) % 4 == 0 and (N - N // 64 * 64) % 8 == 0
+            and dy2.is_contiguous() and Wt.is_contiguous() and Wt.shape[1] == N):
         return _dgrad_long_reduction(dy2, Wt)
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
     k_gemm(dy2, Wt, dx, M, K, N, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.dt(dy2), act=act, aux=aux,
@@ -337,19 +338,27 @@ def _dgrad_long_reduction(dy2, Wt):
     vocabulary projection w.r.t. its input, (1440, 50272) x (50272, 768) (model/layers.py:330-354).  One tile per
     workgroup leaves 72 workgroups walking 786 k-steps each, and 50272 % 64 != 0 sent the whole GEMM to the
     register-staged fallback (982 us, profiles/r03_kernel_stats_D3.csv).  Here: the 64-aligned part of the reduction
-    split across the chip on the direct-to-LDS kernels (fp32 partial sums), the ragged rest (< 64 columns) as a small
-    accumulate on top, one cast."""
+    split across the chip on the direct-to-LDS kernels, every split writing its fp32 partial sum to a slab of its own
+    (HeroGemmEpilogue.split_stride), the ragged rest (< 64 columns) as one more slab, and ONE fold in slab order that also
+    rounds to bf16 (hero_fold_slabs) - bit-reproducible (round 4 merged the splits with fp32 atomics: ADVICE r4)."""
     M, N = dy2.shape
     K = Wt.shape[0]
     n1 = N // 64 * 64
-    out = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
     tiles = -(-M // 128) * -(-K // 128)
     split = max(1, min(n1 // 64 // 8, 16, -(-512 // tiles)))
-    k_gemm(dy2, Wt, out, M, K, n1, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.BF16, out_f32=True, beta=0.0, split_k=split)
+    n_main = L.lib().hero_gemm_splits(n1, split, L.BF16)
+    stride = M * K
+    slabs = torch.empty((n_main + (1 if n1 < N else 0), M, K), dtype=torch.float32, device=dy2.device)
+    if n_main > 1:
+        k_gemm(dy2, Wt, slabs, M, K, n1, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.BF16, out_f32=True, split_k=split, split_stride=stride)
+    else:
+        k_gemm(dy2, Wt, slabs, M, K, n1, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.BF16, out_f32=True)
     if n1 < N:
-        k_gemm(L.ptr(dy2) + 2 * n1, L.ptr(Wt) + 2 * n1, out, M, K, N - n1, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.BF16,
-               out_f32=True, beta=1.0)
-    return k_cast(out, torch.bfloat16)
+        k_gemm(L.ptr(dy2) + 2 * n1, L.ptr(Wt) + 2 * n1, L.ptr(slabs) + 4 * n_main * stride, M, K, N - n1, N, N, K,
+               L.LAYOUT_K, L.LAYOUT_K, L.BF16, out_f32=True)
+    out = torch.empty((M, K), dtype=torch.bfloat16, device=dy2.device)
+    L.check(L.lib().hero_fold_slabs(L.ptr(slabs), slabs.shape[0], stride, L.ptr(out), stride, L.BF16, L.stream()))
+    return out
 
 
 def _split_for(n_out, n_in, rows, bk):
@@ -387,13 +396,14 @@ def _split_for(n_out, n_in, rows, bk):
 # count changes, and by an autograd-engine callback at the end of the backward pass, so nothing outside ever sees a
 # pending gradient.  `on_done` (gradient-sink finality for the bucketed all-reduce) runs when the launch is issued.
 # The queue keeps dY / X alive until then (~1 GB for HERO-base at 12000 rows).
-B1_EPILOGUE = [os.environ.get("HERO_B1_EPILOGUE", "") != ""]      # HERO_B1_EPILOGUE=1: FFN1 bias gradient from the gelu' epilogue's fp32 atomics (rounds 1-3; A/B)
-GELU_SAVE_U = [os.environ.get("HERO_GELU_SAVE_U", "") != ""]      # HERO_GELU_SAVE_U=1: FFN1 saves the pre-activation as in rounds 1-3 (A/B)
-DETERMINISTIC_SCATTER = [os.environ.get("HERO_ATOMIC_SCATTER", "") == ""]    # HERO_ATOMIC_SCATTER=1: the fp32-atomic embedding scatter of rounds 1-3 (A/B)
+# Module-level switches below are for lab scripts and tests (set from Python); none of them is read from the environment.
+# The package's environment variables are listed in README.md ("Environment variables") and checked by
+# tests/test_cpu_boundary.py::test_the_package_reads_only_documented_environment_variables.
 _WQ = []
 _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
-GROUP_WGRADS = [os.environ.get("HERO_NOGROUP", "") == ""]      # HERO_NOGROUP=1: one launch per weight gradient (A/B runs)
-WGRAD_BATCH = [int(os.environ.get("HERO_WGRAD_BATCH", "32"))]   # 4: the per-layer stream-K launches of round 2
+GROUP_WGRADS = [True]       # False: one launch per weight gradient (lab A/B)
+WGRAD_BATCH = [32]          # 4: the per-layer stream-K launches of round 2 (lab A/B)
+WGRAD_DBIAS_RIDE = [True]   # False: bias gradients as (deferred) column sums of their own instead of riding on hero_wgrad_batch (lab A/B)
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5
 _WQ_BYTES = [0]                                                  # sizes its batch to 90 % of HBM: there it flushes at once)
 _WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) or None when the group is too small
@@ -499,11 +509,18 @@ def colsum_flush():
         # one launch must not hold the same destination twice (the fold's read-add-write of dst is not atomic): a
         # parameter used twice in the forward pass (the sub-token embedding LayerNorm: subtitles and queries) goes into
         # consecutive launches, which the stream orders
-        part, seen = [], set()
-        while _CQ and len(part) < 64 and _CQ[0][1].dst not in seen:
-            e = _CQ.pop(0)
-            seen.add(e[1].dst)
-            part.append(e)
+        # ... and "the same destination" means overlapping ADDRESS RANGES, not equal pointers: a problem with
+        # indexed destination rows (HeroColsum.dst_rows) covers its whole table from the table base, a constant-row
+        # problem on the same table starts at base + row * D - one launch would mix the former's atomicAdd with the
+        # latter's plain read-add-write on the same addresses
+        part, seen = [], []
+        while _CQ and len(part) < 64:
+            lo = _CQ[0][1].dst
+            hi = lo + 4 * _CQ[0][2].numel()
+            if any(lo < b and a < hi for a, b in seen):
+                break
+            seen.append((lo, hi))
+            part.append(_CQ.pop(0))
         n = len(part)
         probs = (L.Colsum * n)(*[e[1] for e in part])
         need = L.lib().hero_colsum_multi_workspace_bytes(probs, n) // 4
@@ -543,7 +560,7 @@ def wgrad_flush():
                                       dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32), None)
         plan = _wgrad_plan(probs, n, rows, group[0][0].device) if dtype == torch.bfloat16 else None
         if plan is not None:
-            ride = os.environ.get("HERO_WGRAD_DBIAS", "1") != "0"       # 0: separate (deferred) column sums, for A/B runs
+            ride = WGRAD_DBIAS_RIDE[0]
             for i, e in enumerate(group):                   # bias gradients ride on the dY panels of the batch kernel
                 probs[i].dbias = L.ptr(e[6]) if ride else None
                 if not ride and e[6] is not None:
@@ -710,7 +727,7 @@ def k_ln_bwd(x2, dy2, gamma, mean, rstd, want_dx=True, want_params=True, drop_ou
     return dx, (dxd if dxd is not None else dx), dg, db
 
 
-ATTN_SAVE_PROBS = os.environ.get("HERO_ATTN_SAVE_PROBS", "0") == "1"     # A/B switch: keep the fp32 probabilities for the backward
+ATTN_SAVE_PROBS = False     # tests: keep the fp32 probabilities for the backward instead of the softmax row statistics
 
 
 def k_attn_fwd(qkv, mask_add, S, Lq, H, drop=None, want_probs=True, out=None, seq_off=None):
@@ -1068,7 +1085,7 @@ class EmbedLnFn(torch.autograd.Function):
                         continue
                     folded = k_colsum(dx.view(dx.shape[0] // per, per * dx.shape[1]))
                     k_scatter_add(folded.view(per, dx.shape[1]), idx[:per], SINK.dst(tab), None, skip)
-                elif (DETERMINISTIC_SCATTER[0] and idx.dtype == torch.int32 and idx.is_contiguous() and dx.shape[1] % 4 == 0
+                elif (idx.dtype == torch.int32 and idx.is_contiguous() and dx.shape[1] % 4 == 0
                         and dx.shape[0] <= (1 << 17)):      # (beyond: a 6 KB-per-32-rows workspace; config 5 keeps the atomics)
                     k_scatter_add_sorted(dx, idx.view(-1), SINK.dst(tab).view(-1, tab.shape[-1]), skip)
                 else:
@@ -1273,7 +1290,7 @@ class ProjResLnFn(torch.autograd.Function):
         return (dh, dy.view(ctx.rshape)) + (None,) * 6
 
 
-ONE_ATTN_LAUNCH = [os.environ.get("HERO_ATTN_PER_GROUP", "") == ""]     # HERO_ATTN_PER_GROUP=1: one attention launch per sequence group (A/B)
+ONE_ATTN_LAUNCH = [True]    # False: one attention launch per sequence group (lab A/B)
 _SEQ_OFF = {}
 
 
@@ -1395,7 +1412,7 @@ class FfnBlockFn(torch.autograd.Function):
         # come out of one evaluation of Phi, and the backward epilogue becomes a multiply (HERO_ACT_MUL_AUX: ~7 us of exp /
         # rcp / polynomial per 12000 x 3072 launch, tools/lab/gelu_ab.py)
         u = torch.empty((a2.shape[0], W1.shape[0]), dtype=a2.dtype, device=a2.device)
-        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU if GELU_SAVE_U[0] else L.ACT_GELU_DG, aux=u)
+        hg = k_linear(a2, W1, b1.detach(), act=L.ACT_GELU_DG, aux=u)
         y2 = k_linear(hg, W2, b2.detach(), residual=a2, drop=drop_hid)
         out, mean, rstd, _ = k_ln_fwd(y2, g2.detach(), bt2.detach(), eps, y2.dtype, y2.shape[0], y2.shape[1])
         ctx.drop, ctx.shp = drop_hid, shp
@@ -1423,8 +1440,8 @@ class FfnBlockFn(torch.autograd.Function):
         # two places that made a step's result depend on the order atomics landed in.  Only where the weight gradients go
         # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
         # would be a 74 MB column-sum launch per layer.
-        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0] or B1_EPILOGUE[0])
-        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_GELU_BWD if GELU_SAVE_U[0] else L.ACT_MUL_AUX, aux=u,    # * gelu'(pre-activation) = the saved tensor, fused
+        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0])
+        du = k_dgrad_t(dy2d, W2_t, act=L.ACT_MUL_AUX, aux=u,    # * gelu'(pre-activation) = the saved tensor, fused
                        colsum=SINK.dst(b1) if fuse_b1 else None)
         acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)
         if fuse_b1:

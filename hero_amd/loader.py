@@ -16,7 +16,6 @@ staging -> static on the compute stream and rebuilds everything derived from the
     memoised derived tensors          hero_amd.functional.refresh_memo
 Only batches of the SAME padded shape can share a captured step (ragged batches of varying shape run eagerly through
 PrefetchLoader)."""
-import os
 
 import torch
 
@@ -177,6 +176,7 @@ class StaticBatchFeeder:
         self.copy_stream = torch.cuda.Stream(self.device)
         self._landed = [torch.cuda.Event(), torch.cuda.Event()]
         self._consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        self.skip_h2d = False     # lab switch (tools/lab/feedprobe.py): prefetch() does everything but the transfers
         self._fill = 0            # staging set the next prefetch writes
         self._ready = []          # staging sets that hold a prefetched, not yet committed batch (FIFO)
         self._graph = [None, None]
@@ -202,7 +202,7 @@ class StaticBatchFeeder:
         self._fill ^= 1
         self._ready.append(s)
         self._consumed[s].synchronize()                                  # host-side; never recorded -> returns at once
-        if os.environ.get("HERO_FEED_NO_H2D"):                           # lab switch: everything but the transfers
+        if self.skip_h2d:                                                # lab switch (tools/lab/feedprobe.py): everything but the transfers
             self._landed[s].record(self.copy_stream)
             return
         with torch.cuda.stream(self.copy_stream):

@@ -32,6 +32,11 @@ enum { HERO_F32 = 0, HERO_BF16 = 1 };
 enum { HERO_OK = 0, HERO_ERR_ARG = -1, HERO_ERR_LAUNCH = -2, HERO_ERR_UNSUPPORTED = -3 };
 
 const char* hero_last_error(void);
+/* ABI version of the structs and entry points below; a binding compiled against another version must refuse to run
+ * (hero_amd/_lib.py does).  History: 1 = rounds 1-3.  2 = INCOMPATIBLE struct changes of round 4 - HeroQueryPool.dw is
+ * [B, D] and OVERWRITTEN (was [D], accumulated), HeroStEd gained the required zero-initialised `ws`, HeroColsum gained
+ * row_cols / dst_rows - plus the round-5 additions (hero_probe_*, HeroAdamWMulti.shadow tables). */
+#define HERO_ABI_VERSION 2
 int hero_abi_version(void);
 
 /* Counter-based dropout. keep(element) is a pure function of (*seed_ptr, site, element index), so
@@ -77,6 +82,10 @@ typedef struct HeroGemmEpilogue {
                         /* written to C, before rounding).  K,K operands, no split_k.  Gives the     */
                         /* bias gradient of the layer whose output gradient this GEMM produces        */
                         /* (dH = (dY W2) * gelu'(u) -> db1) without another pass over dH.             */
+  long long split_stride; /* split_k > 1 only.  0: the splits merge with fp32 atomics into C (order-dependent).      */
+                        /* != 0 (elements, >= (M-1) ldc + N): split s WRITES its partial sum to the fp32 slab        */
+                        /* C + s * split_stride (no pre-scale, beta ignored); the number of slabs written is the      */
+                        /* return value of hero_gemm_splits(); hero_fold_slabs adds them in slab order (deterministic) */
 } HeroGemmEpilogue;
 
 /* C[M,N] = op(A)[M,K] * op(B)[K,N] (+ epilogue).
@@ -87,6 +96,11 @@ typedef struct HeroGemmEpilogue {
  * vector width. */
 int hero_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
               int a_layout, int b_layout, int dtype, const HeroGemmEpilogue* epi, hero_stream_t stream);
+/* The number of k-ranges hero_gemm actually cuts a reduction of length K into when asked for `split_k` (whole k-tiles
+ * of 64 (bf16) / 32 (f32) per range, no empty range): the slab count of a split_stride launch. */
+int hero_gemm_splits(int K, int split_k, int dtype);
+/* out[i] = sum_{s < n_slabs} slabs[s * stride + i], s ascending (fixed order), i < n (n % 4 == 0); out_dtype F32 / BF16. */
+int hero_fold_slabs(const float* slabs, int n_slabs, size_t stride, void* out, size_t n, int out_dtype, hero_stream_t stream);
 
 /* Per-launch timing of hero_gemm with HIP events recorded on the launch stream (bench.py's
  * roofline leg; off by default, never enable inside graph capture).

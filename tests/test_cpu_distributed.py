@@ -388,3 +388,35 @@ def test_meta_loader_single_process_contract():
         if len(got) == 400:
             break
     assert ml.step == 400 and 0.65 < got.count("b") / 400 < 0.85           # ratio 3 : 1
+
+
+def test_bench_launch_command_for_a_plain_gpus_n():
+    """`python bench.py --gpus N` without a launcher re-executes itself as the driver's own N > 1 command line (VERDICT r4
+    next #1): one process per GPU under torch.distributed.run on 127.0.0.1; with fewer devices than ranks the ranks share
+    device 0 over gloo (a plumbing run)."""
+    import importlib
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in _sys.path:
+        _sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    cmd, env = bench.launch_command(8, ["--gpus", "8", "--steps", "20"], n_devices=8, port=29500)
+    assert cmd[:3] == [_sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "8", "--steps", "20"]
+    assert env["MASTER_ADDR"] == "127.0.0.1" and "HERO_BENCH_ONE_DEVICE" not in env and env["HSA_ENABLE_IPC_MODE_LEGACY"]
+    cmd, env = bench.launch_command(2, ["--gpus", "2"], n_devices=1)
+    assert env["HERO_BENCH_ONE_DEVICE"] == "1" and env["HERO_BENCH_BACKEND"] == "gloo"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    # under a launcher (WORLD_SIZE set) or with one GPU asked for, nothing is re-executed
+    import argparse
+    old = dict(os.environ)
+    try:
+        os.environ["WORLD_SIZE"] = "2"
+        assert bench.self_launch(argparse.Namespace(gpus=2)) is None
+        os.environ.pop("WORLD_SIZE")
+        os.environ.pop("RANK", None)
+        assert bench.self_launch(argparse.Namespace(gpus=1)) is None
+    finally:
+        os.environ.clear()
+        os.environ.update(old)

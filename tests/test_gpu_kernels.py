@@ -173,8 +173,8 @@ def test_gemm_skinny_f32(HF, Lb, M, N, K):
 
 
 def test_gemm_small_m_heuristic_takes_the_64_row_tiles(HF, Lb):
-    """hero_gemm's own choice for M = 1920, N = 768 (K >= 512) is the 64 x 128 geometry: bit-equal to forcing it, and
-    HERO_WS_SMALL_M is the documented switch back (read once per process, so only the default is checked here)."""
+    """hero_gemm's own choice for M = 1920, N = 768 (K >= 512) is the 64 x 128 geometry: bit-equal to forcing it
+    (`hero_gemm_force_config(8)` is the way back to the 4-wave kernels)."""
     dtype = torch.bfloat16
     for K in (768, 3072):
         x, w, b = rnd(1920, K, dtype=dtype, seed=1), rnd(768, K, dtype=dtype, seed=2, scale=0.05), rnd(768, seed=3)
@@ -185,31 +185,6 @@ def test_gemm_small_m_heuristic_takes_the_64_row_tiles(HF, Lb):
         finally:
             Lb.lib().hero_gemm_force_config(-1)
         assert torch.equal(y, y13)
-
-
-@pytest.mark.parametrize("M,N,K,cfg", [(12000, 2304, 768, 11), (2500, 3072, 768, 11), (7000, 776, 1024, 11), (5000, 3072, 768, 12),
-                                       (1000, 392, 640, 12), (12000, 768, 3072, 11)])
-def test_gemm_wave_specialised_deferred_epilogue(HF, Lb, M, N, K, cfg):
-    """gemm_wsd.hip (round 4): the finished tile is parked in the loader waves' registers and drained during the next tile's
-    main loop (the workgroup's last tile behind dummy ring steps).  Several tiles per workgroup (756 tiles on 256), one
-    tile per workgroup, fewer tiles than workgroups, row / column tails, both geometries - against the 4-wave kernels
-    and fp32 torch like the in-line family, and bit-equal to the in-line family (same arithmetic, same rounding points)."""
-    _ws_against_4wave(HF, Lb, M, N, K, cfg, colsum=False)
-    dtype = torch.bfloat16
-    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=0.05), rnd(N, seed=3)
-    res = rnd(M, N, dtype=dtype, seed=4)
-    drop = HF.RNG.make(0.1, True, x.device)
-    outs = []
-    for c in (cfg - 2, cfg):
-        Lb.lib().hero_gemm_force_config(c)
-        try:
-            aux = torch.empty((M, N), dtype=dtype, device=x.device)
-            outs.append([HF.k_linear(x, w, b, residual=res, drop=drop), HF.k_linear(x, w, b, act=Lb.ACT_GELU, aux=aux), aux,
-                         HF.k_dgrad_t(x, w, act=Lb.ACT_GELU_BWD, aux=res)])
-        finally:
-            Lb.lib().hero_gemm_force_config(-1)
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_)
 
 
 def test_gemm_wave_specialised_large_row_counts(HF, Lb):

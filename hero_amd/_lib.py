@@ -17,7 +17,7 @@ LAYOUT_K, LAYOUT_O = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DG, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_gemm_force_config", "hero_layernorm_fwd",
+    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_probe_mfma", "hero_probe_hbm", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
@@ -194,6 +194,8 @@ def lib():
         L.hero_prof_enable.argtypes = [C.c_int]
         L.hero_prof_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_longlong)]
+        L.hero_probe_mfma.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
+        L.hero_probe_hbm.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
         L.hero_layernorm_fwd.argtypes = [C.POINTER(LnFwd), C.c_void_p]
         L.hero_layernorm_bwd.argtypes = [C.POINTER(LnBwd), C.c_void_p]
         L.hero_layernorm_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int]

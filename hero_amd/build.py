@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libhero_hip.so")
-SOURCES = ["api.cpp", "comm.cpp", "gemm.hip", "gemm_ws.hip", "layernorm.hip", "attention.hip", "attention_mfma.hip", "attention_mfma_long.hip", "rows.hip", "head.hip", "loss.hip", "collate.hip"]
+SOURCES = ["api.cpp", "comm.cpp", "gemm.hip", "gemm_ws.hip", "layernorm.hip", "attention.hip", "attention_mfma.hip", "attention_mfma_long.hip", "rows.hip", "head.hip", "loss.hip", "collate.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

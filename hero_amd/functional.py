@@ -404,6 +404,7 @@ _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [True]       # False: one launch per weight gradient (lab A/B)
 WGRAD_BATCH = [32]          # 4: the per-layer stream-K launches of round 2 (lab A/B)
 WGRAD_DBIAS_RIDE = [True]   # False: bias gradients as (deferred) column sums of their own instead of riding on hero_wgrad_batch (lab A/B)
+B1_EPILOGUE = [False]       # True: the FFN1 bias gradient from the gelu' GEMM epilogue's fp32 atomics, as in rounds 1-3 (lab A/B)
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5
 _WQ_BYTES = [0]                                                  # sizes its batch to 90 % of HBM: there it flushes at once)
 _WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) or None when the group is too small
@@ -1440,7 +1441,7 @@ class FfnBlockFn(torch.autograd.Function):
         # two places that made a step's result depend on the order atomics landed in.  Only where the weight gradients go
         # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
         # would be a 74 MB column-sum launch per layer.
-        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0])
+        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0] or B1_EPILOGUE[0])
         du = k_dgrad_t(dy2d, W2_t, act=L.ACT_MUL_AUX, aux=u,    # * gelu'(pre-activation) = the saved tensor, fused
                        colsum=SINK.dst(b1) if fuse_b1 else None)
         acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)

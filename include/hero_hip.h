@@ -139,13 +139,25 @@ int hero_wgrad_batch(const HeroWgradProblem* probs, int n, int K, int dtype, con
 int hero_gemm_force_config(int cfg); /* tuning hook, bits 0-1 tile geometry: 0 128x128, 1 192x128, 2 256x256,
                                       * 3 64x64 (1 and 3: direct-to-LDS path only); bit 2: register staging;
                                       * bits 8+: M-tiles per L2 locality group; 8 / 9 / 10: the wave-specialised
-                                      * kernels never / always with 192x192 / always with 128x192 tiles; 11 / 12: the
-                                      * latter two with the deferred epilogue; 13 / 14: 64x128 (six-deep ring) / 64x192
+                                      * kernels never / always with 192x192 / always with 128x192 tiles (11 / 12 were
+                                      * round 4's deferred-epilogue lab variant: now plain 4-wave); 13 / 14: 64x128 (six-deep ring) / 64x192
                                       * (four-deep) tiles - what small-M GEMMs (the Temporal Transformer's 1920 rows into
-                                      * N = 768, the 480 query rows) take by default, HERO_WS_SMALL_M=0 turns that off;
+                                      * N = 768, the 480 query rows) take by default;
                                       * -1 heuristic (fp32 GEMMs with M <= 32 then run a skinny VALU kernel) */
 int hero_prof_enable(int on);
 int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* launches);
+
+/* Box probes (bench.py: `roofline.peak_measured`, `.hbm_peak_measured`, `.clock_ghz`): what this box's matrix pipes and HBM
+ * deliver right now.  These two entries TIME themselves with HIP events and synchronise `stream` (like hero_prof_read);
+ * never call them under stream capture.
+ * hero_probe_mfma: ~0.2 s of back-to-back v_mfma_f32_32x32x16_bf16 on every CU (8 waves per CU, 9 accumulators per wave,
+ *   no memory traffic; the first ~70 ms after idle run at ramping clocks and are not timed): dense bf16 TFLOP/s and the
+ *   sustained shader clock.  scratch: device memory, >= CUs * 2048 + 16 bytes.
+ * hero_probe_hbm: a streaming copy src -> dst and a streaming read of src over `bytes` (>= 256 MiB each, beyond the
+ *   Infinity Cache): copy_gbps = (bytes read + bytes written) / time, read_gbps = bytes / time.  dst[0..3] may be written
+ *   by the read pass. */
+int hero_probe_mfma(void* scratch, size_t scratch_bytes, double* tflops, double* ghz, hero_stream_t stream);
+int hero_probe_hbm(const void* src, void* dst, size_t bytes, double* copy_gbps, double* read_gbps, hero_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* LayerNorm (apex FusedLayerNorm call sites: model/layers.py:52,79,171,246,338,               */

@@ -2,18 +2,18 @@
 # kernel stats of the secondary workloads, the bench lines.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out; mkdir -p $OUT
-TAG=${1:-r04}
+TAG=${1:-r05}
 bash tools/profile_run.sh $TAG > $OUT/${TAG}_run.log 2>&1
 export TMPDIR=/tmp
 R=$PWD
 for w in D2r D3; do
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_$w -o s -- python $R/bench.py --workload $w --steps 4 --warmup 2 --no-graph > /dev/null 2> $R/$OUT/${TAG}_stats_$w.log)
   # micro-steps in the trace: D2r 2 (prepare) + 2 (warm-up) + 4; D3: 4 tasks x (2 + 2 + 4)
-  python tools/profile_summary.py stats $OUT/${TAG}_stats_$w $([ $w = D3 ] && echo 32 || echo 8) $OUT/${TAG}_kernel_stats_$w.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload $w --steps 4 --warmup 2 --no-graph (MI355X)"
+  python tools/profile_summary.py steady $OUT/${TAG}_stats_$w 1 $OUT/${TAG}_kernel_stats_$w.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload $w --steps 4 --warmup 2 --no-graph (MI355X)"
   find $OUT/${TAG}_stats_$w -name "*kernel_trace.csv" -delete
 done
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_D4 -o s -- python $R/bench.py --workload D4 --videos 256 --steps 2 --warmup 2 > /dev/null 2> $R/$OUT/${TAG}_stats_D4.log)
-python tools/profile_summary.py stats $OUT/${TAG}_stats_D4 6 $OUT/${TAG}_kernel_stats_D4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload D4 --videos 256 --steps 2 --warmup 2 (MI355X; 256 videos x 256 frames per step)"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/${TAG}_stats_D4 -o s -- python $R/bench.py --workload D4 --videos 256 --steps 4 --warmup 2 > /dev/null 2> $R/$OUT/${TAG}_stats_D4.log)
+python tools/profile_summary.py steady $OUT/${TAG}_stats_D4 1 $OUT/${TAG}_kernel_stats_D4.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload D4 --videos 256 --steps 4 --warmup 2 (MI355X; 256 videos x 256 frames per step)"
 find $OUT/${TAG}_stats_D4 -name "*kernel_trace.csv" -delete
 # idle time between the kernels of the hipGraph replay (tools/lab/graph_gaps.py)
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/${TAG}_gaps -o g -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --profile-steps 0 > /dev/null 2> $R/$OUT/${TAG}_gaps.log)

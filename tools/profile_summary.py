@@ -2,10 +2,14 @@
 """Condense rocprofv3 output into the small summaries committed under profiles/.
 
   python tools/profile_summary.py stats <dir-with-*_kernel_stats.csv> <micro-steps-in-trace> <out.csv> ["header note"]
+  python tools/profile_summary.py steady <dir-with-*_kernel_trace.csv> <optimiser-steps-to-skip> <out.csv> ["header note"]
   python tools/profile_summary.py pmc <fetch-dir> <write-dir> <out.json>
   python tools/profile_summary.py mfma <pmc-dir> <out.json>
 
 `stats`: per-kernel calls / total ms / average us PER MICRO-STEP from `rocprofv3 --kernel-trace --stats`.
+`steady`: the same table from the per-dispatch kernel trace, over STEADY-STATE micro-steps only: the window
+        from the (skip+1)-th to the last `adamw_multi_kernel` launch = whole optimiser steps of 2 micro-steps each, so the
+        one-time fills / copies / lazy-state launches of the first steps (and of model construction) are not averaged in.
 `pmc`:  per-kernel average FETCH_SIZE / WRITE_SIZE (KB, as rocprofv3 reports them; collected in two
         separate --pmc passes because the TCC block cannot hold both) and the corrected HBM bytes per
         launch: FETCH_SIZE x 2 (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md
@@ -40,6 +44,38 @@ def stats(d, steps, out, note=""):
                                                    float(r["TotalDurationNs"]) / steps / 1e6,
                                                    float(r["AverageNs"]) / 1e3, r["Percentage"]))
     print("kernel time %.2f ms/step -> %s" % (total, out))
+
+
+def steady(d, skip, out, note="", accum=2):
+    rows = []
+    with open(_one(d, "*kernel_trace.csv")) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if "adamw_multi_kernel" in r[2]]
+    skip = int(skip)
+    if len(marks) - skip < 2:
+        raise SystemExit("steady: %d optimiser steps in the trace, cannot skip %d" % (len(marks), skip))
+    a, b = marks[skip], marks[-1]
+    seg = rows[a:b]                                   # [AdamW #skip, AdamW #last): whole optimiser steps
+    steps = float((len(marks) - 1 - skip) * accum)
+    acc = collections.OrderedDict()
+    for s_, e_, n in seg:
+        v = acc.setdefault(n, [0, 0])
+        v[0] += 1
+        v[1] += e_ - s_
+    total = sum(v[1] for v in acc.values())
+    span = rows[b][0] - rows[a][0]
+    with open(out, "w") as f:
+        if note:
+            f.write("# %s\n" % note)
+        f.write("# STEADY STATE: %g micro-steps between optimiser steps %d and %d of the trace (the first %d optimiser steps and "
+                "everything before them are skipped); kernel time %.3f ms/step in %.1f launches/step, wall span %.3f ms/step\n"
+                % (steps, skip + 1, len(marks), skip, total / steps / 1e6, len(seg) / steps, span / steps / 1e6))
+        f.write("name,calls_per_step,total_ms_per_step,avg_us,pct\n")
+        for n, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            f.write('"%s",%.1f,%.3f,%.2f,%.4f\n' % (n, c / steps, t / steps / 1e6, t / c / 1e3, 100.0 * t / total))
+    print("steady state: kernel time %.3f ms/step, %.1f launches/step -> %s" % (total / steps / 1e6, len(seg) / steps, out))
 
 
 def _counter(d, name):
@@ -104,6 +140,8 @@ if __name__ == "__main__":
         mfma(*sys.argv[2:])
     elif sys.argv[1] == "stats":
         stats(*sys.argv[2:])
+    elif sys.argv[1] == "steady":
+        steady(*sys.argv[2:])
     elif sys.argv[1] == "pmc":
         pmc(*sys.argv[2:])
     else:

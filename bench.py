@@ -42,8 +42,15 @@ SLOT_NAMES = {4: "gemm_glds_kernel<bf16> (4-wave tiles, K-contiguous operands: t
                  "of the M = 12000 row batch, fused epilogues)",
               9: "gemm_ws_kernel<3,3,O,O> (wave-specialised 192x192 wgrad dY^T X)",
               10: "gemm_ws_kernel<2,3,K,K> (wave-specialised 128x192 tiles: the 1920-row GEMMs with N >= 2304)"}
-PROFILE_TRAFFIC = os.environ.get("HERO_PROFILE_TRAFFIC", "r04_pmc_traffic.json")   # stamped with the kernel-source hash
-PROFILE_MFMA = os.environ.get("HERO_PROFILE_MFMA", "r04_pmc_mfma.json")
+def _latest_profile(suffix):
+    """The newest committed PMC summary (profiles/rNN_<suffix>); it is stamped with the kernel-source hash it was taken with."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return os.path.basename(hits[-1]) if hits else "r04_" + suffix
+
+
+PROFILE_TRAFFIC = os.environ.get("HERO_PROFILE_TRAFFIC") or _latest_profile("pmc_traffic.json")
+PROFILE_MFMA = os.environ.get("HERO_PROFILE_MFMA") or _latest_profile("pmc_mfma.json")
 HBM_PEAK_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s achievable)
 
 

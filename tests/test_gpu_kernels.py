@@ -480,6 +480,57 @@ def test_dgrad_long_reduction_small_output(HF, Lb, M, N, K):
     assert dx.dtype == torch.bfloat16 and dx.shape == (M, K)
     ref = dy.float() @ wt.float().t()
     close(dx, ref, torch.bfloat16, scale=float(ref.abs().max()))
+    # round 5: the splits write slabs (HeroGemmEpilogue.split_stride) that ONE fold adds in slab order - no
+    # atomics, so the result is the same bits run after run
+    for _ in range(3):
+        assert torch.equal(HF.k_dgrad_t(dy, wt), dx)
+
+
+def test_gemm_split_slabs_and_fold(HF, Lb):
+    """split_k with split_stride: split s writes its own fp32 slab, hero_gemm_splits says how many there are,
+    hero_fold_slabs sums them in slab order (fp32 and bf16 outputs) - equal to the unsplit GEMM up to summation order,
+    bit-reproducible; bad strides are refused."""
+    import ctypes as C
+    M, N, K = 256, 512, 64 * 37                     # 37 k-tiles: 8 asked -> ceil(37 / 5) = 8 ranges of 5 (last: 2)
+    a = rnd(M, K, dtype=torch.bfloat16, seed=1)
+    b = rnd(N, K, dtype=torch.bfloat16, seed=2, scale=0.05)
+    n = Lb.lib().hero_gemm_splits(K, 8, Lb.BF16)
+    assert n == 8 and Lb.lib().hero_gemm_splits(K, 1, Lb.BF16) == 1 and Lb.lib().hero_gemm_splits(64, 8, Lb.BF16) == 1
+    slabs = torch.full((n, M, N), float("nan"), device="cuda")
+    HF.k_gemm(a, b, slabs, M, N, K, K, K, N, Lb.LAYOUT_K, Lb.LAYOUT_K, Lb.BF16, out_f32=True, split_k=8, split_stride=M * N)
+    ref = a.float() @ b.float().t()
+    assert torch.isfinite(slabs).all()
+    torch.testing.assert_close(slabs.sum(0), ref, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(slabs[0], a[:, :320].float() @ b[:, :320].float().t(), rtol=1e-4, atol=1e-3)    # slab 0 = k-tiles 0..4
+    for dt_ in (torch.float32, torch.bfloat16):
+        out = torch.empty((M, N), dtype=dt_, device="cuda")
+        Lb.check(Lb.lib().hero_fold_slabs(Lb.ptr(slabs), n, M * N, Lb.ptr(out), M * N, Lb.dt(out), Lb.stream()))
+        want = slabs[0].clone()
+        for k in range(1, n):
+            want += slabs[k]
+        assert torch.equal(out, want.to(dt_))
+    epi = Lb.GemmEpilogue(None, None, None, Lb.ACT_NONE, 1, 0.0, 8, Lb.no_dropout(), None, M * N - 8)      # slab too small
+    assert Lb.lib().hero_gemm(Lb.ptr(a), Lb.ptr(b), Lb.ptr(slabs), M, N, K, K, K, N, 0, 0, Lb.BF16, C.byref(epi), Lb.stream()) != 0
+    epi = Lb.GemmEpilogue(None, None, None, Lb.ACT_NONE, 1, 0.0, 1, Lb.no_dropout(), None, M * N)          # stride without a split
+    assert Lb.lib().hero_gemm(Lb.ptr(a), Lb.ptr(b), Lb.ptr(slabs), M, N, K, K, K, N, 0, 0, Lb.BF16, C.byref(epi), Lb.stream()) != 0
+
+
+def test_box_probes_report_sane_peaks(Lb):
+    """hero_probe_mfma / hero_probe_hbm (bench.py's `box` block): an MI355X delivers ~2.3-2.5 PFLOP/s of dense bf16 MFMA at
+    ~2.1-2.4 GHz and 4-6.5 TB/s of streaming copy; generous brackets, the point is that the numbers are physical."""
+    import ctypes as C
+    n = 1 << 28
+    a = torch.zeros(n // 4, device="cuda")
+    b = torch.empty_like(a)
+    tf, ghz, cp, rd = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    Lb.check(Lb.lib().hero_probe_mfma(Lb.ptr(b), n, C.byref(tf), C.byref(ghz), Lb.stream()))
+    Lb.check(Lb.lib().hero_probe_hbm(Lb.ptr(a), Lb.ptr(b), n, C.byref(cp), C.byref(rd), Lb.stream()))
+    print("box: %.0f TFLOP/s at %.2f GHz, copy %.0f GB/s, read %.0f GB/s" % (tf.value, ghz.value, cp.value, rd.value))
+    assert 1200 < tf.value < 2700 and 1.2 < ghz.value < 2.6
+    assert 2000 < cp.value < 8200 and 1500 < rd.value < 8200
+    assert torch.equal(b[4:], a[4:])                        # the copy pass copied (the read pass may touch dst[0..3])
+    assert Lb.lib().hero_probe_hbm(Lb.ptr(a), Lb.ptr(b), 1 << 20, C.byref(cp), C.byref(rd), Lb.stream()) != 0     # too small: inside the Infinity Cache
+    assert Lb.lib().hero_probe_mfma(Lb.ptr(b), 64, C.byref(tf), C.byref(ghz), Lb.stream()) != 0
 
 
 def test_deferred_weight_gradients_same_destination_twice(HF, Lb):

@@ -319,7 +319,7 @@ def feed_run(device, rank, steps, warmup, n_batches=4):
 
 def box_probe(device):
     """What THIS box delivers right now (the same tree ran 6.37-7.49 ms per step on different boxes of the
-    pool): ~0.2 s of back-to-back bf16 MFMAs on every CU (hero_probe_mfma: dense TFLOP/s, sustained shader clock) and a
+    pool): ~0.2 s of back-to-back bf16 MFMAs on every CU (hero_probe_mfma: dense TFLOP/s, sustained matrix clock) and a
     1 GiB streaming copy / read (hero_probe_hbm).  Runs before the timed region; the constants 2500 TFLOP/s / 8000 GB/s stay
     the `peak` the fractions are quoted against, the measured figures ride beside them."""
     from hero_amd import _lib as L
@@ -333,7 +333,7 @@ def box_probe(device):
     torch.cuda.synchronize()
     del a, b
     torch.cuda.empty_cache()
-    return {"mfma_bf16_tflops": round(tf.value, 1), "shader_clock_ghz": round(ghz.value, 3),
+    return {"mfma_bf16_tflops": round(tf.value, 1), "mfma_clock_ghz": round(ghz.value, 3),
             "hbm_copy_gbps": round(cp.value, 1), "hbm_read_gbps": round(rd.value, 1),
             "how": "hero_probe_mfma: 36 independent v_mfma_f32_32x32x16_bf16 per iteration on 8 waves x every CU, past the clock ramp; "
                    "hero_probe_hbm: 1 GiB nontemporal streaming copy (read + written bytes) and read"}
@@ -592,7 +592,7 @@ def main():
                     "peak_measured": box.get("mfma_bf16_tflops") if box and slot >= 4 else None,
                     "frac_of_peak_measured": round(ach / box["mfma_bf16_tflops"], 4) if box and box.get("mfma_bf16_tflops") and slot >= 4 else None,
                     "hbm_peak_measured": box.get("hbm_copy_gbps") if box else None,
-                    "clock_ghz": box.get("shader_clock_ghz") if box else None,
+                    "clock_ghz": box.get("mfma_clock_ghz") if box else None,
                     "counters_source": "profiles/%s + profiles/%s (rocprofv3 --pmc passes of this command)" % (PROFILE_TRAFFIC, PROFILE_MFMA)}
     elif world > 1:
         for _ in range(args.profile_steps):

@@ -39,7 +39,7 @@ class Dropout(C.Structure):
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("aux", C.c_void_p),
                 ("act", C.c_int), ("out_f32", C.c_int), ("beta", C.c_float),
-                ("split_k", C.c_int), ("dropout", Dropout), ("colsum", C.c_void_p), ("split_stride", C.c_longlong)]
+                ("split_k", C.c_int), ("dropout", Dropout), ("colsum", C.c_void_p), ("colsum_partial", C.c_int), ("pad_", C.c_int), ("split_stride", C.c_longlong)]
 
 
 class CrossEntropy(C.Structure):

@@ -412,7 +412,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         const float4 p = *reinterpret_cast<const float4*>(lc + k * BN + c4);
         t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
       }
-      atomicAdd(e.colsum + gn, t.x); atomicAdd(e.colsum + gn + 1, t.y); atomicAdd(e.colsum + gn + 2, t.z); atomicAdd(e.colsum + gn + 3, t.w);
+      if (e.colsum_partial) {                      // deterministic partial table [ceil(M / 64), N] (hero_hip.h): row m0 / 64, zeros below
+        float* pr = e.colsum + (size_t)(m0 >> 6) * g.N + gn;
+        const int nb = min(BM >> 6, ((g.M + 63) >> 6) - (m0 >> 6));
+        *reinterpret_cast<float4*>(pr) = t;
+        for (int b = 1; b < nb; ++b) *reinterpret_cast<float4*>(pr + (size_t)b * g.N) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        atomicAdd(e.colsum + gn, t.x); atomicAdd(e.colsum + gn + 1, t.y); atomicAdd(e.colsum + gn + 2, t.z); atomicAdd(e.colsum + gn + 3, t.w);
+      }
     }
   }
 }

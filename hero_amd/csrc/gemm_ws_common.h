@@ -406,7 +406,16 @@ __device__ __forceinline__ void epilogue_rows(const WsArgs& g, const Item& ic, c
         float t = 0.f;
 #pragma unroll 4
         for (int k = 0; k < RPI; ++k) t += sp[k * BN + tid];
-        atomicAdd(e.colsum + ic.n0 + tid, t);
+        if (e.colsum_partial) {
+          // deterministic: this tile's sums go to row (m0 / 64) of the [ceil(M / 64), N] partial table, zeros to the rows of
+          // the tile's other 64-row blocks - whatever the tile height, the table's column sums are the result
+          float* pr = e.colsum + (size_t)(ic.m0 >> 6) * g.N + ic.n0 + tid;
+          const int nb = min(G::BM >> 6, ((g.M + 63) >> 6) - (ic.m0 >> 6));
+          pr[0] = t;
+          for (int b = 1; b < nb; ++b) pr[(size_t)b * g.N] = 0.f;
+        } else {
+          atomicAdd(e.colsum + ic.n0 + tid, t);
+        }
       }
       // the next writer of the spare region is the next tile's fold, >= one step barrier away
     }

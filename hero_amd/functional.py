@@ -290,10 +290,11 @@ def _p(t):
 
 
 def k_gemm(A, B, Cm, M, N, K, lda, ldb, ldc, al, bl, dtype_code, bias=None, residual=None,
-           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None, colsum=None, split_stride=0):
+           aux=None, act=L.ACT_NONE, out_f32=False, beta=0.0, split_k=1, drop=None, colsum=None, split_stride=0,
+           colsum_partial=False):
     """A/B/Cm may be tensors or raw device pointers (int) for column-sliced operands."""
     epi = L.GemmEpilogue(_p(bias), _p(residual), _p(aux), act, 1 if out_f32 else 0,
-                         beta, split_k, _d(drop), _p(colsum), split_stride)
+                         beta, split_k, _d(drop), _p(colsum), 1 if colsum_partial else 0, 0, split_stride)
     L.check(L.lib().hero_gemm(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, al, bl,
                               dtype_code, C.byref(epi), L.stream()))
 
@@ -318,9 +319,10 @@ def k_dgrad(dy2, Wc, act=L.ACT_NONE, aux=None, residual=None):
     return dx
 
 
-def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None, colsum=None):
+def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None, colsum=None, colsum_partial=False):
     """dx[M,K] = epilogue(dy2[M,N] @ Wt[K,N]^T) with the transposed weight copy: both operands
-    reduction-contiguous -> the direct-to-LDS GEMM path.  colsum (fp32 [K]) += column sums of dx."""
+    reduction-contiguous -> the direct-to-LDS GEMM path.  colsum (fp32 [K]) += column sums of dx (fp32 atomics), or with
+    colsum_partial a [ceil(M / 64), K] table of per-tile sums that is overwritten (deterministic, HeroGemmEpilogue)."""
     M, N = dy2.shape
     K = Wt.shape[0]
     if (dy2.dtype == torch.bfloat16 and act == L.ACT_NONE and aux is None and residual is None and colsum is None
@@ -329,7 +331,7 @@ def k_dgrad_t(dy2, Wt, act=L.ACT_NONE, aux=None, residual=None, colsum=None):
         return _dgrad_long_reduction(dy2, Wt)
     dx = torch.empty((M, K), dtype=dy2.dtype, device=dy2.device)
     k_gemm(dy2, Wt, dx, M, K, N, N, N, K, L.LAYOUT_K, L.LAYOUT_K, L.dt(dy2), act=act, aux=aux,
-           residual=residual, colsum=colsum)
+           residual=residual, colsum=colsum, colsum_partial=colsum_partial)
     return dx
 
 
@@ -405,6 +407,7 @@ GROUP_WGRADS = [True]       # False: one launch per weight gradient (lab A/B)
 WGRAD_BATCH = [32]          # 4: the per-layer stream-K launches of round 2 (lab A/B)
 WGRAD_DBIAS_RIDE = [True]   # False: bias gradients as (deferred) column sums of their own instead of riding on hero_wgrad_batch (lab A/B)
 B1_EPILOGUE = [False]       # True: the FFN1 bias gradient from the gelu' GEMM epilogue's fp32 atomics, as in rounds 1-3 (lab A/B)
+B1_PARTIALS = [True]        # False: round 4's ride on hero_wgrad_batch (lab A/B); True: per-tile partial sums from the gelu' epilogue
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5
 _WQ_BYTES = [0]                                                  # sizes its batch to 90 % of HBM: there it flushes at once)
 _WPLANS = {}             # (rows, ((M, N), ...)) -> (device int32 plan, words) or None when the group is too small
@@ -1436,15 +1439,21 @@ class FfnBlockFn(torch.autograd.Function):
         if fuse_b:
             SINK.done(b2)
         acc_linear_grads(dy2d, hg, w2, None if fuse_b else b2)
-        # db1 = column sums of du.  Round 4: they ride on the batched weight-gradient launch (hero_wgrad_batch takes them from
-        # the du panels it streams anyway, in a fixed order) instead of fp32 atomics from this GEMM's epilogue - one of the
-        # two places that made a step's result depend on the order atomics landed in.  Only where the weight gradients go
-        # out layer by layer (boundary micro-steps of a data-parallel run) the epilogue sums stay: there the ride
-        # would be a 74 MB column-sum launch per layer.
-        fuse_b1 = b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0] or B1_EPILOGUE[0])
+        # db1 = column sums of du.  Rounds 1-3: fp32 atomics from this GEMM's gelu' epilogue (order-dependent).  Round 4: they
+        # rode on the batched weight-gradient launch (deterministic, but 3072 more bias columns through hero_wgrad_batch's
+        # loader waves cost that launch +0.09 ms per micro-step: tools/lab/ab_wgrad.py, profiles/r05_wgrad_ab.txt).  Round 5:
+        # the epilogue writes each tile's column sums to a [rows / 64, 3072] table (HeroGemmEpilogue.colsum_partial: plain
+        # stores, no atomics) and the table is folded in fixed order - by the deferred multi-sum of the backward pass, or at
+        # once where gradients must become final layer by layer (boundary micro-steps of a data-parallel run).
+        part = None
+        if b1.requires_grad and B1_PARTIALS[0] and dy2d.dtype == torch.bfloat16:
+            part = torch.empty((-(-dy2d.shape[0] // 64), W2_t.shape[0]), dtype=torch.float32, device=dy2d.device)
+        fuse_b1 = part is None and b1.requires_grad and (SINK.wants_overlap() or not GROUP_WGRADS[0] or B1_EPILOGUE[0])
         du = k_dgrad_t(dy2d, W2_t, act=L.ACT_MUL_AUX, aux=u,    # * gelu'(pre-activation) = the saved tensor, fused
-                       colsum=SINK.dst(b1) if fuse_b1 else None)
-        acc_linear_grads(du, a2, w1, None if fuse_b1 else b1)
+                       colsum=part if part is not None else (SINK.dst(b1) if fuse_b1 else None), colsum_partial=part is not None)
+        if part is not None:
+            k_colsum(part, out=SINK.dst(b1), beta=1.0, on_done=lambda: SINK.done(b1))
+        acc_linear_grads(du, a2, w1, None if (fuse_b1 or part is not None) else b1)
         if fuse_b1:
             SINK.done(b1)
         da = k_dgrad_t(du, W1_t, residual=dy2).view(ctx.shp)        # + residual-path gradient, fused

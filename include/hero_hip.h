@@ -82,6 +82,12 @@ typedef struct HeroGemmEpilogue {
                         /* written to C, before rounding).  K,K operands, no split_k.  Gives the     */
                         /* bias gradient of the layer whose output gradient this GEMM produces        */
                         /* (dH = (dY W2) * gelu'(u) -> db1) without another pass over dH.             */
+  int colsum_partial;   /* 0: `colsum` is [N], accumulated with fp32 atomics (order-dependent).  1: `colsum` is a   */
+                        /* [ceil(M / 64), N] fp32 table that is OVERWRITTEN - every output tile writes its column     */
+                        /* sums to row (first tile row / 64) and zeros to the rows of its other 64-row blocks; the     */
+                        /* table's column sums (hero_colsum / hero_colsum_multi, fixed order) are the result:          */
+                        /* bit-reproducible, no atomics.  Needs tile heights that are multiples of 64 (all kernels).    */
+  int pad_;
   long long split_stride; /* split_k > 1 only.  0: the splits merge with fp32 atomics into C (order-dependent).      */
                         /* != 0 (elements, >= (M-1) ldc + N): split s WRITES its partial sum to the fp32 slab        */
                         /* C + s * split_stride (no pre-scale, beta ignored); the number of slabs written is the      */
@@ -152,7 +158,7 @@ int hero_prof_read(int slot, double* total_ms, double* total_flops, long long* l
  * never call them under stream capture.
  * hero_probe_mfma: ~0.2 s of back-to-back v_mfma_f32_32x32x16_bf16 on every CU (8 waves per CU, 9 accumulators per wave,
  *   no memory traffic; the first ~70 ms after idle run at ramping clocks and are not timed): dense bf16 TFLOP/s and the
- *   sustained shader clock.  scratch: device memory, >= CUs * 2048 + 16 bytes.
+ *   sustained matrix clock (from the MFMA occupancy: 32 pipe cycles per 32x32x16 bf16 MFMA).  scratch: device memory, >= CUs * 2048 + 16 bytes.
  * hero_probe_hbm: a streaming copy src -> dst and a streaming read of src over `bytes` (>= 256 MiB each, beyond the
  *   Infinity Cache): copy_gbps = (bytes read + bytes written) / time, read_gbps = bytes / time.  dst[0..3] may be written
  *   by the read pass. */

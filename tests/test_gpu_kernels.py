@@ -470,6 +470,38 @@ def test_gemm_gelu_saved_derivative(HF, Lb, dtype, M, N, K):
     close(du, want, dtype, scale=sc)
 
 
+@pytest.mark.parametrize("M,N,K,cfgs", [(12000, 3072, 768, (-1, 9, 10, 8)), (1920, 3072, 768, (-1, 10, 8)), (1000, 768, 3072, (-1, 13, 0, 1, 3)),
+                                          (300, 136, 64, (-1,))])
+def test_gemm_column_sums_as_per_tile_partials(HF, Lb, M, N, K, cfgs):
+    """HeroGemmEpilogue.colsum_partial (round 5): the gelu' epilogue writes each output tile's column sums to row (tile row / 64)
+    of a [ceil(M / 64), N] table (zeros in the rows of the tile's other 64-row blocks) instead of fp32 atomics into [N] - on the
+    wave-specialised geometries and the 4-wave ones; the table's column sums are the bias gradient (fp32 torch), the output is
+    the bits of the atomic variant's, and two runs give identical tables."""
+    dtype = torch.bfloat16
+    dy, wt = rnd(M, K, dtype=dtype, seed=5), rnd(N, K, dtype=dtype, seed=6, scale=0.05)
+    aux = rnd(M, N, dtype=dtype, seed=7)
+    want = ((dy.float() @ wt.float().t()) * aux.float())
+    nb = -(-M // 64)
+    for cfg in cfgs:
+        Lb.lib().hero_gemm_force_config(cfg)
+        try:
+            part = torch.full((nb, N), float("nan"), device="cuda")
+            du = HF.k_dgrad_t(dy, wt, act=Lb.ACT_MUL_AUX, aux=aux, colsum=part, colsum_partial=True)
+            part2 = torch.full((nb, N), float("nan"), device="cuda")
+            HF.k_dgrad_t(dy, wt, act=Lb.ACT_MUL_AUX, aux=aux, colsum=part2, colsum_partial=True)
+            atom = torch.zeros(N, device="cuda")
+            du3 = HF.k_dgrad_t(dy, wt, act=Lb.ACT_MUL_AUX, aux=aux, colsum=atom)
+        finally:
+            Lb.lib().hero_gemm_force_config(-1)
+        assert torch.isfinite(part).all(), cfg                       # every row of the table was written
+        assert torch.equal(part, part2) and torch.equal(du, du3), cfg
+        got = HF.k_colsum(part)
+        ref = du.float().sum(0) if False else want.sum(0)
+        torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2 * float(want.abs().max()) * math.sqrt(M)), cfg
+        torch.testing.assert_close(got, atom, rtol=1e-4, atol=1e-4 * float(atom.abs().max()) + 1e-6)   # same values, other order
+        assert (part != 0).any(1).sum() <= nb and (part[0] != 0).any()
+
+
 @pytest.mark.parametrize("M,N,K", [(1440, 50272, 768), (360, 8200, 768), (1440, 16384, 136)])
 def test_dgrad_long_reduction_small_output(HF, Lb, M, N, K):
     """functional._dgrad_long_reduction: dx = dy @ Wt^T with a vocabulary-long reduction (configs[3]: the MLM decoder's
@@ -526,7 +558,7 @@ def test_box_probes_report_sane_peaks(Lb):
     Lb.check(Lb.lib().hero_probe_mfma(Lb.ptr(b), n, C.byref(tf), C.byref(ghz), Lb.stream()))
     Lb.check(Lb.lib().hero_probe_hbm(Lb.ptr(a), Lb.ptr(b), n, C.byref(cp), C.byref(rd), Lb.stream()))
     print("box: %.0f TFLOP/s at %.2f GHz, copy %.0f GB/s, read %.0f GB/s" % (tf.value, ghz.value, cp.value, rd.value))
-    assert 1200 < tf.value < 2700 and 1.2 < ghz.value < 2.6
+    assert 1200 < tf.value < 2700 and 1.1 < ghz.value < 2.6 and abs(ghz.value * 1024 * 1024 / 1000 - tf.value) < 1.0   # TF/s = 1024 SIMDs x 1024 flop/clk x GHz
     assert 2000 < cp.value < 8200 and 1500 < rd.value < 8200
     assert torch.equal(b[4:], a[4:])                        # the copy pass copied (the read pass may touch dst[0..3])
     assert Lb.lib().hero_probe_hbm(Lb.ptr(a), Lb.ptr(b), 1 << 20, C.byref(cp), C.byref(rd), Lb.stream()) != 0     # too small: inside the Infinity Cache

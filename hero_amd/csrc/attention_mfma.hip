@@ -51,63 +51,131 @@ __device__ __forceinline__ void store_headT(bf16_t* __restrict__ dst, int ld, in
 // the NB = 1 kernel), 2 = only the longer ones (NB = 2 kernel).  A ragged TVR batch has 8-48 rows per subtitle: with one
 // NB = 2 launch every (sequence, head) pair paid for a 64 x 64 tile at one wave per SIMD - 70 / 110 us per layer forward /
 // backward against 16 / 23 us for the same rows at 24 per sequence (profiles/r03_kernel_stats_D2r.csv).
-template <int NB, int WPB, int CLS>
-__global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  // The pair index is uniform across the wave - readfirstlane says so to the compiler: the sequence bounds (and the dropout
-  // seed below) become SCALAR loads issued together, instead of two vector loads each followed by its own s_waitcnt vmcnt(0)
-  // in front of every other load of the wave (and a third serial round trip for the seed behind the first MFMAs).
-  const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (pair >= a.S * a.H) return;                       // wave-uniform; no workgroup barriers below
-  const int s = pair / a.H, h = pair - s * a.H, D = a.H * 64, ld = 3 * D;
-  // packed batches: rows [seq_off[s], seq_off[s+1]); a.L (the maximum) stays the stride of probs / dropout indices
-  const int Lm = a.L, Lp = (Lm + 3) & ~3;
-  const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
-  const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
-  if (L <= 0) return;
-  if ((CLS == 1 && L > 32) || (CLS == 2 && L <= 32)) return;      // wave-uniform: the other launch owns this sequence
-  DropCtx drop(a.dropout);
-  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (32 * NB * RS);
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
-  const bf16_t* kp = qp + D;
-  const bf16_t* vp = qp + 2 * D;
+//
+// Round 5 - PPW pairs per wave, software-pipelined.  Rounds 2-4 gave every (sequence, head) pair a wave of its own:
+// 6144 pairs on 256 CUs x 12-16 resident waves = 1.5 rounds of waves (forward) / 3 rounds (backward, 8 waves per CU
+// by LDS), each round one exposed chain scalar loads -> global loads -> LDS -> MFMAs -> stores: 20 / 36 us per launch
+// where the bytes need 13.6 / 27 at 5.5 TB/s.  Now a wave walks PPW pairs (pair = wave + k * number of waves, so
+// concurrently running waves still touch neighbouring heads of the same rows) and ISSUES the global loads of pair
+// k + 1 before it computes pair k: at most two pairs' operands are in registers, the straight-line code lets the
+// compiler count vmcnt exactly (VMEM operations of a wave complete in order), and the launch is one full round of waves.
+// The arithmetic of a pair is unchanged (same MFMAs on the same operands, same order): results are bit-identical.
 
-  stage_tile<NB>(vp, ld, L, Vs, lane);
+// wave-uniform coordinates of a (sequence, head) pair; all of a wave's pairs are resolved at the kernel start (scalar loads
+// issued together - resolved later, behind wave-uniform branches, the sequence bounds became vector loads with a wait each)
+struct PairCoord { int s, h, row0, L; bool on; };
+template <int CLS>
+__device__ __forceinline__ PairCoord pair_coord(const HeroAttn& a, int pair) {
+  const int P = a.S * a.H;
+  const int pc = pair < P ? pair : P - 1;                 // past the end: harmless loads of the last pair, nothing computed
+  PairCoord c;
+  c.s = pc / a.H;
+  c.h = pc - c.s * a.H;
+  c.row0 = __builtin_amdgcn_readfirstlane(a.seq_off ? a.seq_off[c.s] : c.s * a.L);
+  c.L = __builtin_amdgcn_readfirstlane(a.seq_off ? a.seq_off[c.s + 1] - c.row0 : a.L);
+  c.on = pair < P && c.L > 0 && !((CLS == 1 && c.L > 32) || (CLS == 2 && c.L <= 32));     // the other launch owns the other class
+  return c;
+}
 
-  // ---- S^T[jt][it] = K Q^T
-  f32x16_t sc[NB][NB];
-  {
-    bf16x8_t kf[NB][4], qf[NB][4];
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[t][ks] = gfrag(kp, ld, 32 * t + l31, L, ks, half);
-        qf[t][ks] = gfrag(qp, ld, 32 * t + l31, L, ks, half);
-      }
+// additive key mask of this lane's 16 keys per key tile (accumulator layout: 4 runs of 4 consecutive keys).  Part of a
+// pair's load set - loaded inside the compute phase it forced a wait for EVERYTHING older, the next pair's prefetch included
+// (VMEM operations complete in order).  Four 16-byte loads when the row stride allows it, else 16 scalar ones.
+template <int NB>
+__device__ __forceinline__ void load_mask(const HeroAttn& a, const PairCoord& c, float (&mk)[NB][16], int lane) {
+  const int half = lane >> 5, Lm = a.L, L = c.L > 0 ? c.L : 1;
+  if (!a.mask) {
 #pragma unroll
     for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-      for (int it = 0; it < NB; ++it) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sc[jt][it][e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) sc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[jt][ks], qf[it][ks], sc[jt][it], 0, 0, 0);
-      }
+      for (int r = 0; r < 16; ++r) mk[jt][r] = 0.f;
+    return;
   }
-  // additive key mask of this lane's keys (independent of the query tile)
+  const float* row = a.mask + (size_t)c.s * Lm;
+  if ((Lm & 3) == 0 && ((uintptr_t)a.mask & 15) == 0) {
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j0 = 32 * jt + 8 * q + 4 * half;          // a run past the row (j0 >= Lm >= L) is never used: any in-row address will do
+        const float4 v = *reinterpret_cast<const float4*>(row + min(j0, Lm - 4));
+        mk[jt][4 * q] = v.x; mk[jt][4 * q + 1] = v.y; mk[jt][4 * q + 2] = v.z; mk[jt][4 * q + 3] = v.w;
+      }
+  } else {
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mk[jt][r] = row[min(32 * jt + acc_row(r, half), L - 1)];
+  }
+}
+
+// what a pair's global loads deliver (registers) + its wave-uniform coordinates
+template <int NB>
+struct FwdIn {
+  bf16x8_t kf[NB][4], qf[NB][4];
+  uint4 vr[4 * NB];
   float mk[NB][16];
+  int s, h, row0, L;
+  bool on;
+};
+
+template <int NB>
+__device__ __forceinline__ void fwd_issue(const HeroAttn& a, const PairCoord& pcd, FwdIn<NB>& in, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int s = pcd.s, h = pcd.h, D = a.H * 64, ld = 3 * D;
+  const int row0 = pcd.row0, L = pcd.L;
+  in.s = s; in.h = h; in.row0 = row0; in.L = L; in.on = pcd.on;
+  const int Lc = L > 0 ? L : 1;
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
+  const bf16_t* kp = qp + D;
+  const bf16_t* vp = qp + 2 * D;
+  const int c = (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4 * NB; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    in.vr[it] = *reinterpret_cast<const uint4*>(vp + (size_t)min(r, Lc - 1) * ld + c);
+  }
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      in.kf[t][ks] = gfrag(kp, ld, 32 * t + l31, Lc, ks, half);
+      in.qf[t][ks] = gfrag(qp, ld, 32 * t + l31, Lc, ks, half);
+    }
+  load_mask<NB>(a, pcd, in.mk, lane);
+}
+
+// V rows -> the wave's LDS tile [32 NB][RS], rows >= L zeroed (stage_tile's second half)
+template <int NB>
+__device__ __forceinline__ void fwd_stage(const FwdIn<NB>& in, bf16_t* Vs, int lane) {
+  const int c = (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4 * NB; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    uint4 t = in.vr[it];
+    if (r >= in.L) t = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(Vs + r * RS + c) = t;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void fwd_compute(const HeroAttn& a, const FwdIn<NB>& in, const bf16_t* Vs, const DropCtx& drop, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int s = in.s, h = in.h, row0 = in.row0, L = in.L, D = a.H * 64;
+  const int Lm = a.L, Lp = (Lm + 3) & ~3;
+  // ---- S^T[jt][it] = K Q^T
+  f32x16_t sc[NB][NB];
 #pragma unroll
   for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = 32 * jt + acc_row(r, half);
-      mk[jt][r] = a.mask ? a.mask[(size_t)s * Lm + min(j, L - 1)] : 0.f;
+    for (int it = 0; it < NB; ++it) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[jt][it][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.kf[jt][ks], in.qf[it][ks], sc[jt][it], 0, 0, 0);
     }
+  const float (&mk)[NB][16] = in.mk;                   // additive key mask of this lane's keys (loaded with the pair's operands)
   // V^T fragments: k-slot e of step ks <-> key 32 jt + 16 ks + 4 half + (e & 3) + 8 (e >> 2), i.e. the
   // keys this lane holds in accumulator registers 8 ks .. 8 ks + 7
-  wave_sync_lds();
   bf16x8_t vf[2][NB][2];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -189,45 +257,111 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_fwd_kernel(HeroAttn a) {
   store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, cx, lane);
 }
 
-template <int NB, int WPB, bool RC, int CLS>       // RC: no saved probabilities - rebuilt from q, k and the saved row statistics
-__global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
+template <int NB, int WPB, int CLS, int PPW>       // second bound: waves per SIMD the two-pair kernel must fit (<= 168 registers)
+__global__ __launch_bounds__(64 * WPB, (PPW == 2 ? 3 : 1)) void attn_mfma_fwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = 32 * NB;
-  constexpr int PS = R + 8;                              // [query][key] bf16 row stride (elements)
-  constexpr int WAVE_BYTES = 3 * R * RS * 2 + 2 * R * PS * 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);      // uniform: scalar loads (see the forward kernel)
-  if (pair >= a.S * a.H) return;
-  const int s = pair / a.H, h = pair - s * a.H, D = a.H * 64, ld = 3 * D;
-  const int Lm = a.L, Lp = (Lm + 3) & ~3;
-  const int row0 = a.seq_off ? a.seq_off[s] : s * Lm;
-  const int L = a.seq_off ? a.seq_off[s + 1] - row0 : Lm;
-  if (L <= 0) return;
-  if ((CLS == 1 && L > 32) || (CLS == 2 && L <= 32)) return;      // wave-uniform: the other launch owns this sequence
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // The wave index is uniform - readfirstlane says so to the compiler: the sequence bounds (and the dropout seed) become
+  // SCALAR loads issued together, instead of vector loads each followed by its own s_waitcnt vmcnt(0).
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
+  if (wid >= a.S * a.H) return;                        // wave-uniform; no workgroup barriers below
   DropCtx drop(a.dropout);
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + wave * WAVE_BYTES);
-  bf16_t* Qs = Ks + R * RS;
-  bf16_t* Os = Qs + R * RS;
-  bf16_t* Pl = Os + R * RS;                              // dropped probabilities [i][j]
-  bf16_t* Sl = Pl + R * PS;                              // dS [i][j]
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (32 * NB * RS);
+  // two named register sets, explicit steps (an array of structs indexed by the unrolled loop counter ended up in scratch)
+  const PairCoord c0 = pair_coord<CLS>(a, wid), c1 = pair_coord<CLS>(a, PPW > 1 ? wid + nw : wid),
+                  c2 = pair_coord<CLS>(a, PPW > 2 ? wid + 2 * nw : wid);
+  FwdIn<NB> A, B;
+  fwd_issue<NB>(a, c0, A, lane);
+  if (PPW > 1) fwd_issue<NB>(a, c1, B, lane);                          // next pair's loads fly during this pair
+  fwd_stage<NB>(A, Vs, lane);
+  wave_sync_lds();
+  if (A.on) fwd_compute<NB>(a, A, Vs, drop, lane);
+  if (PPW > 1) {
+    if (PPW > 2) fwd_issue<NB>(a, c2, A, lane);
+    wave_sync_lds();                                   // the previous pair's transpose reads of the tile are done
+    fwd_stage<NB>(B, Vs, lane);
+    wave_sync_lds();
+    if (B.on) fwd_compute<NB>(a, B, Vs, drop, lane);
+  }
+  if (PPW > 2) {
+    wave_sync_lds();
+    fwd_stage<NB>(A, Vs, lane);
+    wave_sync_lds();
+    if (A.on) fwd_compute<NB>(a, A, Vs, drop, lane);
+  }
+}
+
+template <int NB>
+struct BwdIn {
+  uint4 kr[4 * NB], qr[4 * NB], orw[4 * NB];           // K, Q, dO rows as loaded (16 B per lane per 8 rows)
+  bf16x8_t vf[NB][4];                                  // V row fragments, straight from global memory
+  float mk[NB][16];                                    // RC: additive key mask of this lane's keys
+  float2 st[NB];                                       // RC: saved row maximum and 1 / row sum of this lane's query rows
+  int s, h, row0, L;
+  bool on;
+};
+
+template <int NB, bool RC>
+__device__ __forceinline__ void bwd_issue(const HeroAttn& a, const PairCoord& pcd, BwdIn<NB>& in, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int s = pcd.s, h = pcd.h, D = a.H * 64, ld = 3 * D;
+  const int row0 = pcd.row0, L = pcd.L;
+  in.s = s; in.h = h; in.row0 = row0; in.L = L; in.on = pcd.on;
+  const int Lc = L > 0 ? L : 1;
   const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
   const bf16_t* kp = qp + D;
   const bf16_t* vp = qp + 2 * D;
   const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)row0 * D + h * 64;
+  const int c = (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4 * NB; ++it) {
+    const int r = min(it * 8 + (lane >> 3), Lc - 1);
+    in.kr[it] = *reinterpret_cast<const uint4*>(kp + (size_t)r * ld + c);
+    in.qr[it] = *reinterpret_cast<const uint4*>(qp + (size_t)r * ld + c);
+    in.orw[it] = *reinterpret_cast<const uint4*>(op + (size_t)r * D + c);
+  }
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) in.vf[t][ks] = gfrag(vp, ld, 32 * t + l31, Lc, ks, half);
+  if constexpr (RC) {
+    load_mask<NB>(a, pcd, in.mk, lane);
+#pragma unroll
+    for (int it = 0; it < NB; ++it)
+      in.st[it] = *reinterpret_cast<const float2*>(a.stats + ((size_t)(s * a.H + h) * a.L + min(32 * it + l31, Lc - 1)) * 2);
+  }
+}
 
-  stage_tile<NB>(kp, ld, L, Ks, lane);
-  stage_tile<NB>(qp, ld, L, Qs, lane);
-  stage_tile<NB>(op, D, L, Os, lane);
+template <int NB>
+__device__ __forceinline__ void bwd_stage(const BwdIn<NB>& in, bf16_t* Ks, bf16_t* Qs, bf16_t* Os, int lane) {
+  const int c = (lane & 7) * 8;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int it = 0; it < 4 * NB; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    uint4 k4 = in.kr[it], q4 = in.qr[it], o4 = in.orw[it];     // by value: a select between two uint4 objects takes their
+    if (r >= in.L) { k4 = z; q4 = z; o4 = z; }                 // addresses and parks the whole register set in scratch
+    *reinterpret_cast<uint4*>(Ks + r * RS + c) = k4;
+    *reinterpret_cast<uint4*>(Qs + r * RS + c) = q4;
+    *reinterpret_cast<uint4*>(Os + r * RS + c) = o4;
+  }
+}
+
+template <int NB, bool RC>       // RC: no saved probabilities - rebuilt from q, k and the saved row statistics
+__device__ __forceinline__ void bwd_compute(const HeroAttn& a, const BwdIn<NB>& in, bf16_t* Ks, const DropCtx& drop, int lane) {
+  constexpr int R = 32 * NB;
+  constexpr int PS = R + 8;                              // [query][key] bf16 row stride (elements)
+  const int half = lane >> 5, l31 = lane & 31;
+  const int s = in.s, h = in.h, row0 = in.row0, L = in.L, D = a.H * 64, ld = 3 * D;
+  const int Lm = a.L, Lp = (Lm + 3) & ~3;
+  bf16_t* Qs = Ks + R * RS;
+  bf16_t* Os = Qs + R * RS;
+  bf16_t* Pl = Os + R * RS;                              // dropped probabilities [i][j]
+  bf16_t* Sl = Pl + R * PS;                              // dS [i][j]
 
   // ---- dP^T[jt][it] = V dO^T (dP w.r.t. the DROPPED probabilities)
   f32x16_t dp[NB][NB];
   {
-    bf16x8_t vf[NB][4];
-#pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) vf[t][ks] = gfrag(vp, ld, 32 * t + l31, L, ks, half);
-    wave_sync_lds();
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       bf16x8_t of[4];
@@ -238,7 +372,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) dp[jt][it][e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dp[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jt][ks], of[ks], dp[jt][it], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) dp[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(in.vf[jt][ks], of[ks], dp[jt][it], 0, 0, 0);
       }
     }
   }
@@ -246,7 +380,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   // forward's, then the same scale / mask / exp / normalise with the saved row maximum and 1 / row sum: bit-identical P.
   constexpr bool recompute = RC;
   f32x16_t sc[RC ? NB : 1][RC ? NB : 1];
-  float mk[RC ? NB : 1][16];
+  const float (&mk)[NB][16] = in.mk;
   if constexpr (RC) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
@@ -262,13 +396,6 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
           sc[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lfrag(Ks, 32 * jt + l31, ks, half), qf[ks], sc[jt][it], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int jt = 0; jt < NB; ++jt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = 32 * jt + acc_row(r, half);
-        mk[jt][r] = a.mask ? a.mask[(size_t)s * Lm + min(j, L - 1)] : 0.f;
-      }
   }
   // K^T fragments for dQ (same key <-> k-slot assignment as the forward's V^T)
   bf16x8_t kf[2][NB][2];
@@ -296,7 +423,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
     // each followed by s_waitcnt vmcnt(0): 16 serial round trips per 32-row block.
     const float rowok = i < L ? 1.f : 0.f;
     if constexpr (RC) {
-      const float2 st = *reinterpret_cast<const float2*>(a.stats + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * 2);
+      const float2 st = in.st[it];
 #pragma unroll
       for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
@@ -405,24 +532,80 @@ __global__ __launch_bounds__(64 * WPB) void attn_mfma_bwd_kernel(HeroAttn a) {
   store_headT<NB>(dq + 2 * D, ld, L, gv, lane);
 }
 
-template <int NB, int WPB, int CLS>
-int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
+template <int NB, int WPB, bool RC, int CLS, int PPW>       // second bound: at least two waves per SIMD (<= 256 registers) for the multi-pair kernels
+__global__ __launch_bounds__(64 * WPB, (PPW > 1 ? 2 : 1)) void attn_mfma_bwd_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 32 * NB;
+  constexpr int WAVE_BYTES = 3 * R * RS * 2 + 2 * R * (R + 8) * 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;      // uniform: scalar loads (see the forward kernel)
+  if (wid >= a.S * a.H) return;
+  DropCtx drop(a.dropout);
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + wave * WAVE_BYTES);
+  const PairCoord c0 = pair_coord<CLS>(a, wid), c1 = pair_coord<CLS>(a, PPW > 1 ? wid + nw : wid),
+                  c2 = pair_coord<CLS>(a, PPW > 2 ? wid + 2 * nw : wid);
+  BwdIn<NB> A, B;
+  bf16_t* Qs = Ks + R * RS;
+  bf16_t* Os = Qs + R * RS;
+  bwd_issue<NB, RC>(a, c0, A, lane);
+  if (PPW > 1) bwd_issue<NB, RC>(a, c1, B, lane);                      // next pair's loads fly during this pair
+  bwd_stage<NB>(A, Ks, Qs, Os, lane);
+  wave_sync_lds();
+  if (A.on) bwd_compute<NB, RC>(a, A, Ks, drop, lane);
+  if (PPW > 1) {
+    if (PPW > 2) bwd_issue<NB, RC>(a, c2, A, lane);
+    wave_sync_lds();                                   // the previous pair's reads of the tiles are done
+    bwd_stage<NB>(B, Ks, Qs, Os, lane);
+    wave_sync_lds();
+    if (B.on) bwd_compute<NB, RC>(a, B, Ks, drop, lane);
+  }
+  if (PPW > 2) {
+    wave_sync_lds();
+    bwd_stage<NB>(A, Ks, Qs, Os, lane);
+    wave_sync_lds();
+    if (A.on) bwd_compute<NB, RC>(a, A, Ks, drop, lane);
+  }
+}
+
+static int cu_count() {
+  int dev = 0, v = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+  return v > 0 ? v : 256;
+}
+
+template <int NB, int WPB, int CLS, int PPW>
+int launch_ppw(const HeroAttn& a, bool bwd, hipStream_t s) {
   constexpr int R = 32 * NB;
   const int pairs = a.S * a.H;
-  const int grid = (pairs + WPB - 1) / WPB;
+  const int waves = (pairs + PPW - 1) / PPW;
+  const int grid = (waves + WPB - 1) / WPB;
   if (bwd) {
     const size_t lds = (size_t)WPB * (3 * R * RS * 2 + 2 * R * (R + 8) * 2);
     if (lds > 65536) {
-      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, false, CLS>), lds, "attn_mfma_bwd_kernel");
-      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, true, CLS>), lds, "attn_mfma_bwd_kernel");
+      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, false, CLS, PPW>), lds, "attn_mfma_bwd_kernel");
+      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, true, CLS, PPW>), lds, "attn_mfma_bwd_kernel");
     }
-    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
-    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false, CLS, PPW>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true, CLS, PPW>), dim3(grid), dim3(64 * WPB), lds, s, a);
   } else {
     const size_t lds = (size_t)WPB * R * RS * 2;
-    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB, CLS>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB, CLS, PPW>), dim3(grid), dim3(64 * WPB), lds, s, a);
   }
   return check_launch(bwd ? "hero_attention_bwd(mfma)" : "hero_attention_fwd(mfma)");
+}
+
+// Pairs per wave: as many as make the launch ONE round of resident waves - forward 12 per CU (the two-pair kernel holds 152
+// registers: three waves per SIMD), backward 8 per CU (two per SIMD: <= 256 registers, and its 19 KB of LDS tiles per wave
+// allow no more) - at most 3; small launches keep one pair per wave.  The bench batch: 6144 pairs = 2 x 3072 = 3 x 2048.
+template <int NB, int WPB, int CLS>
+int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
+  if (NB == 2) return launch_ppw<NB, WPB, CLS, 1>(a, bwd, s);          // 64-row tiles: registers for one pair only
+  const long slots = (long)cu_count() * (bwd ? 8 : 12);
+  const long pairs = (long)a.S * a.H;
+  const int ppw = pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1);
+  if (ppw == 3) return launch_ppw<NB, WPB, CLS, NB == 2 ? 1 : 3>(a, bwd, s);
+  if (ppw == 2) return launch_ppw<NB, WPB, CLS, NB == 2 ? 1 : 2>(a, bwd, s);
+  return launch_ppw<NB, WPB, CLS, 1>(a, bwd, s);
 }
 
 }  // namespace

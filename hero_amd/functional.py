@@ -12,6 +12,7 @@ Block structure (one autograd node each, residual fan-in fused into GEMM epilogu
 import ctypes as C
 import math
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -766,9 +767,22 @@ def k_attn_bwd(qkv, saved, dctx, S, Lq, H, drop=None, out=None, seq_off=None, ct
     return dqkv
 
 
-def k_gather_rows(a, b, idx, rows, cols):
+_SLACK = {}        # storage address -> weak reference to a row buffer allocated with spare rows behind its result
+
+
+def k_gather_rows(a, b, idx, rows, cols, tail_rows=0):
+    """tail_rows: allocate that many spare rows BEHIND the result (same storage): a following row stack / gradient
+    stack writes its small remaining blocks there instead of copying this (large) block (StackRowsFn, SplitRowsFn)."""
     ref = a if a is not None else b
-    out = torch.empty((rows, cols), dtype=ref.dtype, device=ref.device)
+    if tail_rows > 0:
+        base = torch.empty((rows + tail_rows, cols), dtype=ref.dtype, device=ref.device)
+        _SLACK[base.untyped_storage().data_ptr()] = weakref.ref(base)      # alive as long as any view of it is
+        if len(_SLACK) > 64:
+            for k in [k for k, r in _SLACK.items() if r() is None]:
+                del _SLACK[k]
+        out = base[:rows]
+    else:
+        out = torch.empty((rows, cols), dtype=ref.dtype, device=ref.device)
     L.check(L.lib().hero_gather_rows(L.ptr(a), L.ptr(b), L.ptr(idx), L.ptr(out), rows, cols,
                                      L.dt(ref), L.stream()))
     return out
@@ -1113,14 +1127,37 @@ def embed_ln(x, gamma, beta, eps, drop, out_dtype, tables=(), idxs=(), skip_idx=
     return EmbedLnFn.apply(x, gamma, beta, eps, drop, out_dtype, skip_idx, tuple(idxs), *tables)
 
 
+def _stack_in_place(blocks, rows, cols):
+    """If the FIRST block was allocated with enough spare rows behind it (k_gather_rows(tail_rows=...)), the stacked
+    tensor is that storage: the other (small) blocks are copied into the spare rows and a [sum rows, cols] view over the
+    first block's storage is returned - the large block is not moved.  None if the first block has no such room."""
+    first = blocks[0]
+    total = sum(rows)
+    ref = _SLACK.get(first.untyped_storage().data_ptr()) if first.is_cuda else None
+    base = ref() if ref is not None else None
+    # only a storage that k_gather_rows allocated WITH spare rows - and that is still that allocation (the weak reference
+    # is alive) - qualifies: any other tensor at offset 0 of a larger storage may have live data behind it
+    if not (base is not None and first.is_contiguous() and first.dim() == 2 and first.storage_offset() == 0
+            and base.dtype == first.dtype and base.shape[1] == cols and first.shape[0] == rows[0] and base.shape[0] >= total):
+        return None
+    full = base[:total]
+    r0 = rows[0]
+    for blk, n in zip(blocks[1:], rows[1:]):
+        full[r0:r0 + n].copy_(blk.reshape(n, cols))
+        r0 += n
+    return full
+
+
 class StackRowsFn(torch.autograd.Function):
-    """cat of 2-D row blocks; the backward hands out views of dy (aten's CatBackward does too, this one exists for
-    symmetry with SplitRowsFn and to keep the pair out of the dispatcher)."""
+    """cat of 2-D row blocks; the backward hands out views of dy.  Round 5: when the first block has spare rows behind it
+    (the subtitle embeddings: hero_gather_rows allocates the 480 query rows with them, model/encoder.py) only the
+    remaining blocks are copied - 0.7 MB instead of an 18 MB cat per micro-step."""
 
     @staticmethod
     def forward(ctx, *xs):
         ctx.rows = [x.shape[0] for x in xs]
-        return torch.cat(xs, 0)
+        full = _stack_in_place(xs, ctx.rows, xs[0].shape[1]) if all(x.dtype == xs[0].dtype for x in xs) else None
+        return full if full is not None else torch.cat(xs, 0)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1132,9 +1169,11 @@ class StackRowsFn(torch.autograd.Function):
 
 
 class SplitRowsFn(torch.autograd.Function):
-    """x -> row blocks of the given sizes (views).  backward = ONE cat of the block gradients; aten's slices would
-    each materialise a zero tensor of the full shape, copy their block in and add the results (5 passes over the
-    stacked rows instead of 1: 64 us per micro-step on the sub + query stack of the bench batch)."""
+    """x -> row blocks of the given sizes (views).  backward = ONE stacked gradient; aten's slices would each materialise
+    a zero tensor of the full shape, copy their block in and add the results (5 passes over the stacked rows instead of
+    1).  The first output carries `_hero_tail_rows` = the rows of the other blocks: a consumer whose backward produces the
+    first block's gradient with hero_gather_rows (CsrGatherSumFn) allocates it with that many spare rows, and this
+    backward then copies only the small blocks in (round 5) instead of a cat of everything."""
 
     @staticmethod
     def forward(ctx, x, *sizes):
@@ -1150,18 +1189,19 @@ class SplitRowsFn(torch.autograd.Function):
         cols, dtype, dev = ctx.meta
         parts = [g.reshape(n, cols) if g is not None else torch.zeros((n, cols), dtype=dtype, device=dev)
                  for g, n in zip(grads, ctx.sizes)]
-        return (torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
+        full = _stack_in_place(parts, list(ctx.sizes), cols) if all(p_.dtype == dtype for p_ in parts) else None
+        return (full if full is not None else torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
 
 
 class GatherRowsFn(torch.autograd.Function):
     """out[r] = a[idx[r]] (idx>=0) | 0 (idx==-1) | b[-idx-2]."""
 
     @staticmethod
-    def forward(ctx, a, b, idx):
+    def forward(ctx, a, b, idx, tail_rows=0):
         a2, b2 = _as2d(a), (_as2d(b) if b is not None else None)
         ctx.save_for_backward(idx)
         ctx.ashape, ctx.bshape = a.shape, (b.shape if b is not None else None)
-        return k_gather_rows(a2, b2, idx, idx.numel(), a2.shape[1])
+        return k_gather_rows(a2, b2, idx, idx.numel(), a2.shape[1], tail_rows=tail_rows)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1170,7 +1210,7 @@ class GatherRowsFn(torch.autograd.Function):
         da = torch.zeros(ctx.ashape, dtype=dy.dtype, device=dy.device)
         db = torch.zeros(ctx.bshape, dtype=dy.dtype, device=dy.device) if ctx.bshape is not None else None
         k_scatter_add(dy2, idx, da, db)
-        return da, db, None
+        return da, db, None, None
 
 
 class PermuteRowsFn(torch.autograd.Function):
@@ -1203,13 +1243,14 @@ class CsrGatherSumFn(torch.autograd.Function):
                                             n_out, s2.shape[1], L.dt(s2), L.stream()))
         ctx.save_for_backward(inverse)
         ctx.sshape = src.shape
+        ctx.tail = int(getattr(src, "_hero_tail_rows", 0))      # SplitRowsFn: rows stacked behind this block
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (inverse,) = ctx.saved_tensors
         dy2 = _as2d(dy)
-        ds = k_gather_rows(dy2, None, inverse, inverse.numel(), dy2.shape[1])
+        ds = k_gather_rows(dy2, None, inverse, inverse.numel(), dy2.shape[1], tail_rows=ctx.tail)
         return ds.view(ctx.sshape), None, None, None, None
 
 

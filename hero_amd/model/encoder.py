@@ -142,7 +142,8 @@ class CrossModalTrm(RobertaPreTrainedModel):
 
     def _compute_img_txt_embeddings(self, input_ids, position_ids, img_feat, img_pos_ids,
                                     gather_index, txt_type_ids=None, img_type_ids=None,
-                                    img_masks=None):
+                                    img_masks=None, tail_rows=0):
+        """tail_rows (hero_amd only): spare rows allocated behind the result for the row stack of the fused query pass."""
         txt_emb = img_emb = None
         if input_ids is not None:
             txt_emb = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
@@ -152,7 +153,7 @@ class CrossModalTrm(RobertaPreTrainedModel):
             assert gather_index is not None
             T, Lout = gather_index.shape
             flat = self._flat_gather_index(gather_index, img_emb.shape[1], txt_emb.shape[1])
-            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat)
+            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat, tail_rows)
             return out.view(T, Lout, -1)
         if txt_emb is not None:
             return txt_emb

@@ -314,7 +314,10 @@ class BertEncoder(nn.Module):
         if len(segs) == 1:
             return [x.view(segs[0][0], segs[0][1], D)]
         blocks = HF.SplitRowsFn.apply(x, *[S * Lq for (S, Lq) in segs])
-        return [b.view(S, Lq, D) for b, (S, Lq) in zip(blocks, segs)]
+        outs = [b.view(S, Lq, D) for b, (S, Lq) in zip(blocks, segs)]
+        # the gradient of the first (large) block can be produced with room for the others behind it (functional.SplitRowsFn)
+        outs[0]._hero_tail_rows = sum(S * Lq for (S, Lq) in segs[1:])
+        return outs
 
 
 class BertLMPredictionHead(nn.Module):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Who issues the device-to-device copies (__amd_rocclr_copyBuffer in the kernel trace) of a micro-step: chrome trace of
-two steps; every hipMemcpy* runtime call is matched to the CPU ops that enclose it.  `ragged` = the D2r batch."""
+two steps; every hipMemcpy* runtime call is matched to the CPU ops that enclose it.  `ragged` = the D2r batch, `D4` = configs[4] shapes (96 videos)."""
 import collections, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -16,7 +16,10 @@ cfgp = "/tmp/hero_prof_cfg.json"
 json.dump(bench.HERO_BASE, open(cfgp, "w"))
 model = bench.build_model(dev, cfgp)
 tr = TrainStep(model, use_graph=False, static_usage=True)
-batch = make_batch("D2", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev, ragged="ragged" in sys.argv)
+if "D4" in sys.argv:       # configs[4] shapes at a small batch: 96 videos x 256 frames
+    batch = make_batch("D4", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev, videos=96)
+else:
+    batch = make_batch("D2", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev, ragged="ragged" in sys.argv)
 for _ in range(4):
     tr.micro_step(batch)
 torch.cuda.synchronize()

@@ -751,6 +751,98 @@ def test_attention_packed_sequences(HF, dtype, lens, H):
     torch.testing.assert_close(lhs, rhs, rtol=2e-2 if dtype == torch.bfloat16 else 1e-3, atol=0.5 if dtype == torch.bfloat16 else 1e-2)
 
 
+@pytest.mark.parametrize("S,L,H,packed", [(301, 24, 12, False), (505, 24, 12, False), (410, 31, 12, True), (200, 20, 4, False)])
+def test_attention_several_pairs_per_wave(HF, Lb, S, L, H, packed):
+    """Round 5: launches with more (sequence, head) pairs than one round of resident waves give every wave 2 or 3 pairs and
+    prefetch the next pair's operands (attention_mfma.hip).  The arithmetic of a pair is unchanged: the big launch must give
+    the BITS of the same sequences run in launches of other sizes (other wave <-> pair assignments), forward and backward, with dropout, with the
+    saved row statistics and with saved probabilities, padded and packed (ragged lengths, incl. pairs past the last wave)."""
+    D = H * 64
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(S)
+    lens = [int(x) for x in torch.randint(1, L + 1, (S,), generator=g)] if packed else [L] * S
+    M = sum(lens)
+    qkv, dctx = rnd(M, 3 * D, dtype=dtype, seed=1), rnd(M, D, dtype=dtype, seed=2)
+    off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32).cuda() if packed else None
+    m = (torch.rand(S, L, generator=g) > 0.1).float()
+    m[:, 0] = 1
+    madd = ((1 - m) * -10000.0).cuda()
+    drop = HF.RNG.make(0.1, True, qkv.device)
+    for save_probs in (False, True):
+        HF.ATTN_SAVE_PROBS = save_probs
+        try:
+            ctx, saved = HF.k_attn_fwd(qkv, madd, S, L, H, drop=drop, seq_off=off)
+            dq = HF.k_attn_bwd(qkv, saved, dctx, S, L, H, drop=drop, seq_off=off, ctx=ctx, mask_add=madd)
+            # the same sequences in chunks of 64 - the dropout index of an element depends on
+            # its sequence number, so every chunk is run as sequences [s0, s0 + n) of a launch of s0 + n sequences whose first s0 are
+            # empty (packed form: seq_off = 0 ... 0, then the chunk's bounds)
+            r0 = 0
+            for s0 in range(0, S, 64):
+                n = min(64, S - s0)
+                rows = sum(lens[s0:s0 + n])
+                o = torch.tensor([0] * (s0 + 1) + list(torch.tensor(lens[s0:s0 + n]).cumsum(0)), dtype=torch.int32).cuda()
+                mk = torch.zeros(s0 + n, L, device="cuda")
+                mk[s0:] = madd[s0:s0 + n]
+                c1, sv1 = HF.k_attn_fwd(qkv[r0:r0 + rows].contiguous(), mk, s0 + n, L, H, drop=drop, seq_off=o)
+                d1 = HF.k_attn_bwd(qkv[r0:r0 + rows].contiguous(), sv1, dctx[r0:r0 + rows].contiguous(), s0 + n, L, H, drop=drop, seq_off=o,
+                                   ctx=c1, mask_add=mk)
+                assert torch.equal(ctx[r0:r0 + rows], c1), (save_probs, s0)
+                assert torch.equal(dq[r0:r0 + rows], d1), (save_probs, s0)
+                r0 += rows
+        finally:
+            HF.ATTN_SAVE_PROBS = False
+    # and against fp32 torch (padded case only: one reference for the whole launch)
+    if not packed:
+        ctx, saved = HF.k_attn_fwd(qkv, madd, S, L, H)
+        q = qkv.float()
+        qq, kk, vv = [t.reshape(S, L, H, 64).permute(0, 2, 1, 3) for t in q.split(D, dim=1)]
+        pr = torch.softmax(qq @ kk.transpose(-1, -2) / 8.0 + madd[:, None, None, :], -1)
+        close(ctx, (pr @ vv).permute(0, 2, 1, 3).reshape(S * L, D), dtype)
+
+
+def test_row_stack_and_split_in_place(HF, Lb):
+    """Round 5: the fused query pass stacks the subtitle rows and the query rows.  hero_gather_rows allocates the first (large)
+    block with spare rows behind it, StackRowsFn copies only the small block in; in the backward CsrGatherSumFn does the same
+    for the gradient and SplitRowsFn stacks in place.  Same values as cat / separate gradients; a block that merely sits at the
+    start of a larger tensor is NOT extended (its neighbours are live data)."""
+    dtype = torch.bfloat16
+    a = rnd(300, 64, dtype=dtype, seed=1).requires_grad_(True)
+    b = rnd(37, 64, dtype=dtype, seed=2).requires_grad_(True)
+    idx = torch.randperm(300, generator=torch.Generator().manual_seed(3))[:200].to(torch.int32).cuda()
+    first = HF.GatherRowsFn.apply(a, None, idx, 37)
+    stacked = HF.StackRowsFn.apply(first, b)
+    assert stacked.shape == (237, 64) and stacked.data_ptr() == first.data_ptr()          # the large block did not move
+    assert torch.equal(stacked[:200], a.detach()[idx.long()]) and torch.equal(stacked[200:], b.detach())
+    w = rnd(237, 64, dtype=dtype, seed=4)
+    (stacked.float() * w.float()).sum().backward()
+    ga = torch.zeros(300, 64, device="cuda")
+    ga[idx.long()] = w[:200].float()
+    torch.testing.assert_close(a.grad.float(), ga, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(b.grad.float(), w[200:].float(), rtol=1e-2, atol=1e-2)
+    # no spare rows / a view into a larger live tensor: plain cat, nothing behind the block is touched
+    big = rnd(400, 64, dtype=dtype, seed=5)
+    keep = big.clone()
+    st2 = HF.StackRowsFn.apply(big[:200], b.detach())
+    assert st2.data_ptr() != big.data_ptr() and torch.equal(big, keep)
+    assert torch.equal(st2[:200], big[:200]) and torch.equal(st2[200:], b.detach())
+    # the split's backward: the first block's gradient comes from CsrGatherSumFn with spare rows, the second is copied behind it
+    x = rnd(237, 64, dtype=dtype, seed=6).requires_grad_(True)
+    blocks = HF.SplitRowsFn.apply(x, 200, 37)
+    v0 = blocks[0].view(50, 4, 64)
+    v0._hero_tail_rows = 37
+    offs = torch.arange(0, 101, 2, dtype=torch.int32).cuda()[:51]          # 50 outputs of 2 source rows each (rows 0..99)
+    ent = torch.arange(100, dtype=torch.int32).cuda()
+    inv = torch.full((200,), -1, dtype=torch.int32)
+    inv[:100] = torch.arange(100, dtype=torch.int32) // 2
+    out = HF.CsrGatherSumFn.apply(v0, offs, ent, inv.cuda(), 50)
+    wo, wq = rnd(50, 64, dtype=dtype, seed=7), rnd(37, 64, dtype=dtype, seed=8)
+    ((out.float() * wo.float()).sum() + (blocks[1].float() * wq.float()).sum()).backward()
+    want = torch.zeros(237, 64, device="cuda")
+    want[:100] = wo.float().repeat_interleave(2, 0)
+    want[200:] = wq.float()
+    torch.testing.assert_close(x.grad.float(), want, rtol=1e-2, atol=1e-2)
+
+
 def test_attention_dropout_adjoint(HF, Lb):
     """With dropout on, forward is linear in V for a fixed mask and backward must use the SAME mask:
     <dctx, ctx(V)> == <dV, V>.  Also the keep rate is 1-p."""

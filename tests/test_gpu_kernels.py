@@ -541,9 +541,9 @@ def test_gemm_split_slabs_and_fold(HF, Lb):
         for k in range(1, n):
             want += slabs[k]
         assert torch.equal(out, want.to(dt_))
-    epi = Lb.GemmEpilogue(None, None, None, Lb.ACT_NONE, 1, 0.0, 8, Lb.no_dropout(), None, M * N - 8)      # slab too small
+    epi = Lb.GemmEpilogue(act=Lb.ACT_NONE, out_f32=1, split_k=8, dropout=Lb.no_dropout(), split_stride=M * N - 8)      # slab too small
     assert Lb.lib().hero_gemm(Lb.ptr(a), Lb.ptr(b), Lb.ptr(slabs), M, N, K, K, K, N, 0, 0, Lb.BF16, C.byref(epi), Lb.stream()) != 0
-    epi = Lb.GemmEpilogue(None, None, None, Lb.ACT_NONE, 1, 0.0, 1, Lb.no_dropout(), None, M * N)          # stride without a split
+    epi = Lb.GemmEpilogue(act=Lb.ACT_NONE, out_f32=1, split_k=1, dropout=Lb.no_dropout(), split_stride=M * N)          # stride without a split
     assert Lb.lib().hero_gemm(Lb.ptr(a), Lb.ptr(b), Lb.ptr(slabs), M, N, K, K, K, N, 0, 0, Lb.BF16, C.byref(epi), Lb.stream()) != 0
 
 

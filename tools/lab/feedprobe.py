@@ -44,3 +44,27 @@ ev("payload D2D", lambda: [fd.static[k].copy_(fd.stage[0][k]) for k in fd.shapes
 ev("load_lengths", lambda: fd.dc.load_lengths(fd.stage_len[0], src_device=True))
 ev("rebuild", lambda: fd.dc.rebuild(c_v_feats=fd.static["c_v_feats"]))
 ev("refresh_memo", lambda: HF_refresh())
+# round 5: where do the +0.6 ms of the fed step (7.00 vs 6.40 ms in the driver's run) come from?
+ev("commit graph replay", lambda: fd._graph[0].replay())
+def host_ms(name, fn, n=20):
+    torch.cuda.synchronize(); t = 0.0
+    for i in range(n):
+        t0 = time.perf_counter(); fn(i); t += time.perf_counter() - t0
+        torch.cuda.synchronize()
+    print("  host time of %-18s %.3f ms per call" % (name, t / n * 1e3))
+fd.prefetch(host[1])
+def hc(i):
+    fd.commit(); fd.prefetch(host[i % 4])
+host_ms("commit + prefetch", hc)
+fd.commit()
+host_ms("prefetch alone", lambda i: (fd.prefetch(host[i % 4]), fd.commit()) and None)
+host_ms("step replay launch", lambda i: tr.micro_step(fd.static))
+fd.skip_h2d = True
+fd.prefetch(host[0])
+print("commit+prefetch(no H2D)+step %.3f ms" % T(full))
+fd.commit()
+fd.skip_h2d = False
+fd.prefetch(host[0])
+print("commit+prefetch+step (again) %.3f ms" % T(full, n=40))
+fd.commit()
+print("step only (again) %.3f ms" % T(lambda i: tr.micro_step(fd.static), n=40))

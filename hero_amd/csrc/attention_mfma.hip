@@ -80,31 +80,32 @@ __device__ __forceinline__ PairCoord pair_coord(const HeroAttn& a, int pair) {
 // additive key mask of this lane's 16 keys per key tile (accumulator layout: 4 runs of 4 consecutive keys).  Part of a
 // pair's load set - loaded inside the compute phase it forced a wait for EVERYTHING older, the next pair's prefetch included
 // (VMEM operations complete in order).  Four 16-byte loads when the row stride allows it, else 16 scalar ones.
-template <int NB>
+// M4: rows of a.mask are 16-byte aligned multiples of 4 floats - decided by the LAUNCHER (template parameter): a run-time
+// choice between the two load sets is a join, and the compiler made the wave wait for the loads at the join.
+template <int NB, bool M4>
 __device__ __forceinline__ void load_mask(const HeroAttn& a, const PairCoord& c, float (&mk)[NB][16], int lane) {
   const int half = lane >> 5, Lm = a.L, L = c.L > 0 ? c.L : 1;
-  if (!a.mask) {
-#pragma unroll
-    for (int jt = 0; jt < NB; ++jt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mk[jt][r] = 0.f;
-    return;
-  }
-  const float* row = a.mask + (size_t)c.s * Lm;
-  if ((Lm & 3) == 0 && ((uintptr_t)a.mask & 15) == 0) {
+  // No mask: the loads still happen (from the start of qkv, always mapped) and a select zeroes the values - an `if (!a.mask)`
+  // around the loads is a join of two definitions, and the compiler waits for the loads right there (before the join's copies).
+  const bool has = a.mask != nullptr;
+  const float* row = has ? a.mask + (size_t)c.s * Lm : reinterpret_cast<const float*>(a.qkv);
+  if constexpr (M4) {
 #pragma unroll
     for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int j0 = 32 * jt + 8 * q + 4 * half;          // a run past the row (j0 >= Lm >= L) is never used: any in-row address will do
-        const float4 v = *reinterpret_cast<const float4*>(row + min(j0, Lm - 4));
-        mk[jt][4 * q] = v.x; mk[jt][4 * q + 1] = v.y; mk[jt][4 * q + 2] = v.z; mk[jt][4 * q + 3] = v.w;
+        const float4 v = *reinterpret_cast<const float4*>(row + (has ? min(j0, Lm - 4) : 0));
+        mk[jt][4 * q] = has ? v.x : 0.f; mk[jt][4 * q + 1] = has ? v.y : 0.f; mk[jt][4 * q + 2] = has ? v.z : 0.f; mk[jt][4 * q + 3] = has ? v.w : 0.f;
       }
   } else {
 #pragma unroll
     for (int jt = 0; jt < NB; ++jt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mk[jt][r] = row[min(32 * jt + acc_row(r, half), L - 1)];
+      for (int r = 0; r < 16; ++r) {
+        const float v = row[has ? min(32 * jt + acc_row(r, half), L - 1) : 0];
+        mk[jt][r] = has ? v : 0.f;
+      }
   }
 }
 
@@ -118,14 +119,17 @@ struct FwdIn {
   bool on;
 };
 
-template <int NB>
+template <int NB, bool M4>
 __device__ __forceinline__ void fwd_issue(const HeroAttn& a, const PairCoord& pcd, FwdIn<NB>& in, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
   const int s = pcd.s, h = pcd.h, D = a.H * 64, ld = 3 * D;
   const int row0 = pcd.row0, L = pcd.L;
   in.s = s; in.h = h; in.row0 = row0; in.L = L; in.on = pcd.on;
-  const int Lc = L > 0 ? L : 1;
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
+  // A pair this launch does not own (the other length class of a packed batch, or past the end) is not computed; its loads
+  // stay in the instruction stream - a wave-uniform branch around them made the compiler wait vmcnt(0) behind every issue,
+  // i.e. no prefetch at all - but all go to row 0 of the tensor (one cache line per operand), selected without a branch.
+  const int Lc = pcd.on ? L : 1;
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)(pcd.on ? row0 : 0) * ld + h * 64;
   const bf16_t* kp = qp + D;
   const bf16_t* vp = qp + 2 * D;
   const int c = (lane & 7) * 8;
@@ -141,7 +145,7 @@ __device__ __forceinline__ void fwd_issue(const HeroAttn& a, const PairCoord& pc
       in.kf[t][ks] = gfrag(kp, ld, 32 * t + l31, Lc, ks, half);
       in.qf[t][ks] = gfrag(qp, ld, 32 * t + l31, Lc, ks, half);
     }
-  load_mask<NB>(a, pcd, in.mk, lane);
+  load_mask<NB, M4>(a, pcd, in.mk, lane);
 }
 
 // V rows -> the wave's LDS tile [32 NB][RS], rows >= L zeroed (stage_tile's second half)
@@ -257,7 +261,7 @@ __device__ __forceinline__ void fwd_compute(const HeroAttn& a, const FwdIn<NB>& 
   store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, cx, lane);
 }
 
-template <int NB, int WPB, int CLS, int PPW>       // second bound: waves per SIMD the two-pair kernel must fit (<= 168 registers)
+template <int NB, int WPB, int CLS, int PPW, bool M4>       // second bound: waves per SIMD the two-pair kernel must fit (<= 168 registers)
 __global__ __launch_bounds__(64 * WPB, (PPW == 2 ? 3 : 1)) void attn_mfma_fwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -271,13 +275,13 @@ __global__ __launch_bounds__(64 * WPB, (PPW == 2 ? 3 : 1)) void attn_mfma_fwd_ke
   const PairCoord c0 = pair_coord<CLS>(a, wid), c1 = pair_coord<CLS>(a, PPW > 1 ? wid + nw : wid),
                   c2 = pair_coord<CLS>(a, PPW > 2 ? wid + 2 * nw : wid);
   FwdIn<NB> A, B;
-  fwd_issue<NB>(a, c0, A, lane);
-  if (PPW > 1) fwd_issue<NB>(a, c1, B, lane);                          // next pair's loads fly during this pair
+  fwd_issue<NB, M4>(a, c0, A, lane);
+  if (PPW > 1) fwd_issue<NB, M4>(a, c1, B, lane);                          // next pair's loads fly during this pair
   fwd_stage<NB>(A, Vs, lane);
   wave_sync_lds();
   if (A.on) fwd_compute<NB>(a, A, Vs, drop, lane);
   if (PPW > 1) {
-    if (PPW > 2) fwd_issue<NB>(a, c2, A, lane);
+    if (PPW > 2) fwd_issue<NB, M4>(a, c2, A, lane);
     wave_sync_lds();                                   // the previous pair's transpose reads of the tile are done
     fwd_stage<NB>(B, Vs, lane);
     wave_sync_lds();
@@ -301,17 +305,17 @@ struct BwdIn {
   bool on;
 };
 
-template <int NB, bool RC>
+template <int NB, bool RC, bool M4>
 __device__ __forceinline__ void bwd_issue(const HeroAttn& a, const PairCoord& pcd, BwdIn<NB>& in, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
   const int s = pcd.s, h = pcd.h, D = a.H * 64, ld = 3 * D;
   const int row0 = pcd.row0, L = pcd.L;
   in.s = s; in.h = h; in.row0 = row0; in.L = L; in.on = pcd.on;
-  const int Lc = L > 0 ? L : 1;
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
+  const int Lc = pcd.on ? L : 1;                         // not owned: every load goes to row 0 (see fwd_issue)
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)(pcd.on ? row0 : 0) * ld + h * 64;
   const bf16_t* kp = qp + D;
   const bf16_t* vp = qp + 2 * D;
-  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)row0 * D + h * 64;
+  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)(pcd.on ? row0 : 0) * D + h * 64;
   const int c = (lane & 7) * 8;
 #pragma unroll
   for (int it = 0; it < 4 * NB; ++it) {
@@ -325,7 +329,7 @@ __device__ __forceinline__ void bwd_issue(const HeroAttn& a, const PairCoord& pc
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) in.vf[t][ks] = gfrag(vp, ld, 32 * t + l31, Lc, ks, half);
   if constexpr (RC) {
-    load_mask<NB>(a, pcd, in.mk, lane);
+    load_mask<NB, M4>(a, pcd, in.mk, lane);
 #pragma unroll
     for (int it = 0; it < NB; ++it)
       in.st[it] = *reinterpret_cast<const float2*>(a.stats + ((size_t)(s * a.H + h) * a.L + min(32 * it + l31, Lc - 1)) * 2);
@@ -532,7 +536,7 @@ __device__ __forceinline__ void bwd_compute(const HeroAttn& a, const BwdIn<NB>& 
   store_headT<NB>(dq + 2 * D, ld, L, gv, lane);
 }
 
-template <int NB, int WPB, bool RC, int CLS, int PPW>       // second bound: at least two waves per SIMD (<= 256 registers) for the multi-pair kernels
+template <int NB, int WPB, bool RC, int CLS, int PPW, bool M4>       // second bound: at least two waves per SIMD (<= 256 registers) for the multi-pair kernels
 __global__ __launch_bounds__(64 * WPB, (PPW > 1 ? 2 : 1)) void attn_mfma_bwd_kernel(HeroAttn a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = 32 * NB;
@@ -547,13 +551,13 @@ __global__ __launch_bounds__(64 * WPB, (PPW > 1 ? 2 : 1)) void attn_mfma_bwd_ker
   BwdIn<NB> A, B;
   bf16_t* Qs = Ks + R * RS;
   bf16_t* Os = Qs + R * RS;
-  bwd_issue<NB, RC>(a, c0, A, lane);
-  if (PPW > 1) bwd_issue<NB, RC>(a, c1, B, lane);                      // next pair's loads fly during this pair
+  bwd_issue<NB, RC, M4>(a, c0, A, lane);
+  if (PPW > 1) bwd_issue<NB, RC, M4>(a, c1, B, lane);                      // next pair's loads fly during this pair
   bwd_stage<NB>(A, Ks, Qs, Os, lane);
   wave_sync_lds();
   if (A.on) bwd_compute<NB, RC>(a, A, Ks, drop, lane);
   if (PPW > 1) {
-    if (PPW > 2) bwd_issue<NB, RC>(a, c2, A, lane);
+    if (PPW > 2) bwd_issue<NB, RC, M4>(a, c2, A, lane);
     wave_sync_lds();                                   // the previous pair's reads of the tiles are done
     bwd_stage<NB>(B, Ks, Qs, Os, lane);
     wave_sync_lds();
@@ -567,13 +571,365 @@ __global__ __launch_bounds__(64 * WPB, (PPW > 1 ? 2 : 1)) void attn_mfma_bwd_ker
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 64-row class (32 < L <= 64), round 5: TWO waves per (sequence, head) pair.  The one-wave kernels above hold a 64 x 64
+// problem in one wave: 270-340 registers = one wave per SIMD, four pairs in flight per CU, 28 / 50 us per layer forward /
+// backward on the ragged TVR batch (profiles/r04_kernel_stats_D2r.csv) - a third of its sequences.  Here wave w of a pair
+// owns QUERY tile w for everything that is per query (S^T, softmax, ctx / dP, dS, dQ) and KEY tile w for the two products
+// that contract over the queries (dK, dV); K / Q / dO / V are staged once per pair, half the rows by each wave; workgroup
+// barriers separate the phases.  Same MFMAs on the same operands in the same order as the one-wave kernels: bit-identical
+// results.  One pair per workgroup (128 threads); the backward's P tile reuses the K tile's LDS once both waves have read it
+// (37 KB per pair: four pairs = eight waves per CU).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CLS, bool M4>
+__global__ __launch_bounds__(128, 2) void attn_mfma_fwd2_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+  const PairCoord pc = pair_coord<CLS>(a, __builtin_amdgcn_readfirstlane(blockIdx.x));
+  if (!pc.on) return;                                   // uniform across the WORKGROUP (both waves share the pair): no barrier is skipped by one wave only
+  const int s = pc.s, h = pc.h, row0 = pc.row0, L = pc.L, D = a.H * 64, ld = 3 * D;
+  const int Lm = a.L, Lp = (Lm + 3) & ~3;
+  DropCtx drop(a.dropout);
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem);
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
+  const bf16_t* kp = qp + D;
+  const bf16_t* vp = qp + 2 * D;
+  // ---- loads: this wave's half of the V rows, K fragments of both key tiles, Q fragments of its query tile, the key mask
+  uint4 vr[4];
+  const int c = (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) vr[it] = *reinterpret_cast<const uint4*>(vp + (size_t)min(32 * w + it * 8 + (lane >> 3), L - 1) * ld + c);
+  bf16x8_t kf[2][4], qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[0][ks] = gfrag(kp, ld, l31, L, ks, half);
+    kf[1][ks] = gfrag(kp, ld, 32 + l31, L, ks, half);
+    qf[ks] = gfrag(qp, ld, 32 * w + l31, L, ks, half);
+  }
+  float mk[2][16];
+  load_mask<2, M4>(a, pc, mk, lane);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = 32 * w + it * 8 + (lane >> 3);
+    uint4 t = vr[it];
+    if (r >= L) t = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(Vs + r * RS + c) = t;
+  }
+  // ---- S^T[jt] = K_jt Q_w^T
+  f32x16_t sc[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sc[jt][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[jt][ks], qf[ks], sc[jt], 0, 0, 0);
+  }
+  __syncthreads();                                       // the V tile is staged (both halves)
+  bf16x8_t vf[2][2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r0 = 32 * jt + 16 * ks + 4 * half;
+        vf[dt][jt][ks] = tr_frag(tr_addr(Vs, RS * 2, r0, dt, lane), tr_addr(Vs, RS * 2, r0 + 8, dt, lane));
+      }
+  const int i = 32 * w + l31;
+  float p[2][16];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * jt + acc_row(r, half);
+      const float v = j < L ? fmaf(sc[jt][r], a.scale, mk[jt][r]) : -3.0e38f;
+      p[jt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, xhalf(mx));
+  float sum = 0.f;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * jt + acc_row(r, half);
+      const float e = j < L ? __expf(p[jt][r] - mx) : 0.f;
+      p[jt][r] = e;
+      sum += e;
+    }
+  sum += xhalf(sum);
+  const float inv = 1.f / sum;
+  if (a.stats && half == 0 && i < L)
+    *reinterpret_cast<float2*>(a.stats + ((size_t)(s * a.H + h) * Lm + i) * 2) = make_float2(mx, inv);
+  float* prow = a.probs ? a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm : nullptr;
+  const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j0 = 32 * jt + 8 * q + 4 * half;
+      float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (drop.on()) m = drop.mask4((drow + j0) >> 2);
+      const float mm[4] = {m.x, m.y, m.z, m.w};
+      float pr4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pr4[e] = p[jt][4 * q + e] * inv;
+        p[jt][4 * q + e] = pr4[e] * mm[e];
+      }
+      if (prow && i < L) {
+        if ((Lm & 3) == 0 && j0 + 3 < L) {
+          *reinterpret_cast<float4*>(prow + j0) = make_float4(pr4[0], pr4[1], pr4[2], pr4[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j0 + e < L) prow[j0 + e] = pr4[e];
+        }
+      }
+    }
+  f32x16_t cx[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cx[dt][e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        cx[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][jt][ks], pack8(&p[jt][8 * ks]), cx[dt], 0, 0, 0);
+  }
+  store_tileT(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, w, cx, lane);
+}
+
+template <bool RC, int CLS, bool M4>
+__global__ __launch_bounds__(128, 2) void attn_mfma_bwd2_kernel(HeroAttn a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 64, PS = RS;                          // P / dS tiles [query][key] share the head tiles' row stride
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+  const PairCoord pc = pair_coord<CLS>(a, __builtin_amdgcn_readfirstlane(blockIdx.x));
+  if (!pc.on) return;                                   // uniform across the workgroup
+  const int s = pc.s, h = pc.h, row0 = pc.row0, L = pc.L, D = a.H * 64, ld = 3 * D;
+  const int Lm = a.L, Lp = (Lm + 3) & ~3;
+  DropCtx drop(a.dropout);
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Qs = Ks + R * RS;
+  bf16_t* Os = Qs + R * RS;
+  bf16_t* Sl = Os + R * RS;                              // dS [i][j]
+  bf16_t* Pl = Ks;                                       // dropped probabilities [i][j]: the K tile's LDS, after barrier B
+  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)row0 * ld + h * 64;
+  const bf16_t* kp = qp + D;
+  const bf16_t* vp = qp + 2 * D;
+  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)row0 * D + h * 64;
+  // ---- loads: this wave's half of the K / Q / dO rows, V fragments of both key tiles, mask, row statistics
+  uint4 kr[4], qr[4], orw[4];
+  const int c = (lane & 7) * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = min(32 * w + it * 8 + (lane >> 3), L - 1);
+    kr[it] = *reinterpret_cast<const uint4*>(kp + (size_t)r * ld + c);
+    qr[it] = *reinterpret_cast<const uint4*>(qp + (size_t)r * ld + c);
+    orw[it] = *reinterpret_cast<const uint4*>(op + (size_t)r * D + c);
+  }
+  bf16x8_t vf[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vf[t][ks] = gfrag(vp, ld, 32 * t + l31, L, ks, half);
+  const int i = 32 * w + l31;
+  float mk[2][16];
+  float2 st = make_float2(0.f, 0.f);
+  if constexpr (RC) {
+    load_mask<2, M4>(a, pc, mk, lane);
+    st = *reinterpret_cast<const float2*>(a.stats + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * 2);
+  }
+  {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = 32 * w + it * 8 + (lane >> 3);
+      uint4 k4 = kr[it], q4 = qr[it], o4 = orw[it];
+      if (r >= L) { k4 = z; q4 = z; o4 = z; }
+      *reinterpret_cast<uint4*>(Ks + r * RS + c) = k4;
+      *reinterpret_cast<uint4*>(Qs + r * RS + c) = q4;
+      *reinterpret_cast<uint4*>(Os + r * RS + c) = o4;
+    }
+  }
+  __syncthreads();                                       // A: K, Q, dO staged (both halves)
+  // ---- phase 1, query tile w: dP^T[jt] = V_jt dO_w^T, (RC) S^T[jt] = K_jt Q_w^T
+  f32x16_t dp[2];
+  {
+    bf16x8_t of[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) of[ks] = lfrag(Os, i, ks, half);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dp[jt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jt][ks], of[ks], dp[jt], 0, 0, 0);
+    }
+  }
+  f32x16_t sc[2];
+  if constexpr (RC) {
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = lfrag(Qs, i, ks, half);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[jt][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        sc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lfrag(Ks, 32 * jt + l31, ks, half), qf[ks], sc[jt], 0, 0, 0);
+    }
+  }
+  // K^T fragments for dQ (same key <-> k-slot assignment as the forward's V^T)
+  bf16x8_t kf[2][2][2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r0 = 32 * jt + 16 * ks + 4 * half;
+        kf[dt][jt][ks] = tr_frag(tr_addr(Ks, RS * 2, r0, dt, lane), tr_addr(Ks, RS * 2, r0 + 8, dt, lane));
+      }
+  __syncthreads();                                       // B: both waves are done with the K tile - P may overwrite it
+  bf16_t* dq = static_cast<bf16_t*>(a.dqkv) + (size_t)row0 * ld + h * 64;
+  {
+    const float* prow = RC ? nullptr : a.probs + ((size_t)(s * a.H + h) * Lm + min(i, L - 1)) * Lm;
+    const uint64_t drow = ((uint64_t)(s * a.H + h) * Lm + i) * (uint64_t)Lp;
+    float pr[2][16], ds[2][16];
+    const float rowok = i < L ? 1.f : 0.f;
+    if constexpr (RC) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * jt + acc_row(r, half);
+          const float v = j < L ? fmaf(sc[jt][r], a.scale, mk[jt][r]) : -3.0e38f;
+          const float e = j < L ? __expf(v - st.x) : 0.f;
+          pr[jt][r] = e * st.y * rowok;
+        }
+    } else if ((Lm & 3) == 0) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j0 = 32 * jt + 8 * q + 4 * half;
+          const float4 v = *reinterpret_cast<const float4*>(prow + min(j0, Lm - 4));
+          pr[jt][4 * q + 0] = v.x * (j0 + 0 < L ? rowok : 0.f);
+          pr[jt][4 * q + 1] = v.y * (j0 + 1 < L ? rowok : 0.f);
+          pr[jt][4 * q + 2] = v.z * (j0 + 2 < L ? rowok : 0.f);
+          pr[jt][4 * q + 3] = v.w * (j0 + 3 < L ? rowok : 0.f);
+        }
+    } else {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * jt + acc_row(r, half);
+          pr[jt][r] = prow[min(j, L - 1)] * (j < L ? rowok : 0.f);
+        }
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j0 = 32 * jt + 8 * q + 4 * half;
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (drop.on()) m = drop.mask4((drow + j0) >> 2);
+        const float mm[4] = {m.x, m.y, m.z, m.w};
+        float pd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = dp[jt][4 * q + e] * mm[e];
+          ds[jt][4 * q + e] = g;
+          delta = fmaf(g, pr[jt][4 * q + e], delta);
+          pd[e] = pr[jt][4 * q + e] * mm[e];
+        }
+        st_bf4(Pl + i * PS + j0, pd[0], pd[1], pd[2], pd[3]);
+      }
+    delta += xhalf(delta);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ds[jt][r] = pr[jt][r] * (ds[jt][r] - delta) * a.scale;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        st_bf4(Sl + i * PS + 32 * jt + 8 * q + 4 * half, ds[jt][4 * q], ds[jt][4 * q + 1], ds[jt][4 * q + 2], ds[jt][4 * q + 3]);
+    }
+    f32x16_t gq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gq[dt][e] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          gq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[dt][jt][ks], pack8(&ds[jt][8 * ks]), gq[dt], 0, 0, 0);
+    }
+    store_tileT(dq, ld, L, w, gq, lane);
+  }
+  __syncthreads();                                       // C: P and dS of all 64 queries are in the LDS
+  // ---- phase 2, key tile w: dV^T = dO^T P_dropped, dK^T = Q^T dS over the 64 queries
+  f32x16_t gv[2], gk[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { gv[dt][e] = 0.f; gk[dt][e] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = 32 * it + 16 * ks + 8 * half;
+      bf16x8_t of[2], qf[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        of[dt] = tr_frag(tr_addr(Os, RS * 2, r0, dt, lane), tr_addr(Os, RS * 2, r0 + 4, dt, lane));
+        qf[dt] = tr_frag(tr_addr(Qs, RS * 2, r0, dt, lane), tr_addr(Qs, RS * 2, r0 + 4, dt, lane));
+      }
+      const bf16x8_t pf = tr_frag(tr_addr(Pl, PS * 2, r0, w, lane), tr_addr(Pl, PS * 2, r0 + 4, w, lane));
+      const bf16x8_t sf = tr_frag(tr_addr(Sl, PS * 2, r0, w, lane), tr_addr(Sl, PS * 2, r0 + 4, w, lane));
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        gv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[dt], pf, gv[dt], 0, 0, 0);
+        gk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[dt], sf, gk[dt], 0, 0, 0);
+      }
+    }
+  store_tileT(dq + D, ld, L, w, gk, lane);
+  store_tileT(dq + 2 * D, ld, L, w, gv, lane);
+}
+
+static bool mask_by_fours(const HeroAttn& a) { return !a.mask || ((a.L & 3) == 0 && ((uintptr_t)a.mask & 15) == 0); }
+
+template <int CLS, bool M4>
+int launch2m(const HeroAttn& a, bool bwd, hipStream_t s) {
+  const int pairs = a.S * a.H;
+  if (bwd) {
+    const size_t lds = (size_t)4 * 64 * RS * 2;          // K (then P), Q, dO, dS tiles
+    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd2_kernel<false, CLS, M4>), dim3(pairs), dim3(128), lds, s, a);
+    else hipLaunchKernelGGL((attn_mfma_bwd2_kernel<true, CLS, M4>), dim3(pairs), dim3(128), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_mfma_fwd2_kernel<CLS, M4>), dim3(pairs), dim3(128), (size_t)64 * RS * 2, s, a);
+  }
+  return check_launch(bwd ? "hero_attention_bwd(mfma, 64 rows)" : "hero_attention_fwd(mfma, 64 rows)");
+}
+template <int CLS>
+int launch2(const HeroAttn& a, bool bwd, hipStream_t s) {
+  return mask_by_fours(a) ? launch2m<CLS, true>(a, bwd, s) : launch2m<CLS, false>(a, bwd, s);
+}
+
 static int cu_count() {
   int dev = 0, v = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
   return v > 0 ? v : 256;
 }
 
-template <int NB, int WPB, int CLS, int PPW>
+template <int NB, int WPB, int CLS, int PPW, bool M4>
 int launch_ppw(const HeroAttn& a, bool bwd, hipStream_t s) {
   constexpr int R = 32 * NB;
   const int pairs = a.S * a.H;
@@ -582,14 +938,14 @@ int launch_ppw(const HeroAttn& a, bool bwd, hipStream_t s) {
   if (bwd) {
     const size_t lds = (size_t)WPB * (3 * R * RS * 2 + 2 * R * (R + 8) * 2);
     if (lds > 65536) {
-      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, false, CLS, PPW>), lds, "attn_mfma_bwd_kernel");
-      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, true, CLS, PPW>), lds, "attn_mfma_bwd_kernel");
+      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, false, CLS, PPW, M4>), lds, "attn_mfma_bwd_kernel");
+      HERO_ENSURE_LDS((&attn_mfma_bwd_kernel<NB, WPB, true, CLS, PPW, M4>), lds, "attn_mfma_bwd_kernel");
     }
-    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false, CLS, PPW>), dim3(grid), dim3(64 * WPB), lds, s, a);
-    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true, CLS, PPW>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, false, CLS, PPW, M4>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    else hipLaunchKernelGGL((attn_mfma_bwd_kernel<NB, WPB, true, CLS, PPW, M4>), dim3(grid), dim3(64 * WPB), lds, s, a);
   } else {
     const size_t lds = (size_t)WPB * R * RS * 2;
-    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB, CLS, PPW>), dim3(grid), dim3(64 * WPB), lds, s, a);
+    hipLaunchKernelGGL((attn_mfma_fwd_kernel<NB, WPB, CLS, PPW, M4>), dim3(grid), dim3(64 * WPB), lds, s, a);
   }
   return check_launch(bwd ? "hero_attention_bwd(mfma)" : "hero_attention_fwd(mfma)");
 }
@@ -597,27 +953,29 @@ int launch_ppw(const HeroAttn& a, bool bwd, hipStream_t s) {
 // Pairs per wave: as many as make the launch ONE round of resident waves - forward 12 per CU (the two-pair kernel holds 152
 // registers: three waves per SIMD), backward 8 per CU (two per SIMD: <= 256 registers, and its 19 KB of LDS tiles per wave
 // allow no more) - at most 3; small launches keep one pair per wave.  The bench batch: 6144 pairs = 2 x 3072 = 3 x 2048.
-template <int NB, int WPB, int CLS>
-int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
-  if (NB == 2) return launch_ppw<NB, WPB, CLS, 1>(a, bwd, s);          // 64-row tiles: registers for one pair only
+template <int WPB, int CLS, bool M4>
+int launch_m(const HeroAttn& a, bool bwd, hipStream_t s) {
   const long slots = (long)cu_count() * (bwd ? 8 : 12);
   const long pairs = (long)a.S * a.H;
-  const int ppw = pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1);
-  if (ppw == 3) return launch_ppw<NB, WPB, CLS, NB == 2 ? 1 : 3>(a, bwd, s);
-  if (ppw == 2) return launch_ppw<NB, WPB, CLS, NB == 2 ? 1 : 2>(a, bwd, s);
-  return launch_ppw<NB, WPB, CLS, 1>(a, bwd, s);
+  if (pairs > 2 * slots) return launch_ppw<1, WPB, CLS, 3, M4>(a, bwd, s);
+  if (pairs > slots) return launch_ppw<1, WPB, CLS, 2, M4>(a, bwd, s);
+  return launch_ppw<1, WPB, CLS, 1, M4>(a, bwd, s);
+}
+template <int WPB, int CLS>
+int launch(const HeroAttn& a, bool bwd, hipStream_t s) {
+  return mask_by_fours(a) ? launch_m<WPB, CLS, true>(a, bwd, s) : launch_m<WPB, CLS, false>(a, bwd, s);
 }
 
 }  // namespace
 
 // bf16, 1 <= L <= 64.  Called by attention.hip's dispatcher.
 int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s) {
-  if (a.L <= 32) return launch<1, 4, 0>(a, bwd, s);
+  if (a.L <= 32) return launch<4, 0>(a, bwd, s);
   if (a.seq_off) {                 // packed: two launches, each taking the sequences of its length class
-    const int rc = launch<1, 4, 1>(a, bwd, s);
-    return rc ? rc : launch<2, 1, 2>(a, bwd, s);
+    const int rc = launch<4, 1>(a, bwd, s);
+    return rc ? rc : launch2<2>(a, bwd, s);
   }
-  return launch<2, 1, 0>(a, bwd, s);
+  return launch2<0>(a, bwd, s);
 }
 
 }  // namespace hero

@@ -751,7 +751,8 @@ def test_attention_packed_sequences(HF, dtype, lens, H):
     torch.testing.assert_close(lhs, rhs, rtol=2e-2 if dtype == torch.bfloat16 else 1e-3, atol=0.5 if dtype == torch.bfloat16 else 1e-2)
 
 
-@pytest.mark.parametrize("S,L,H,packed", [(301, 24, 12, False), (505, 24, 12, False), (410, 31, 12, True), (200, 20, 4, False)])
+@pytest.mark.parametrize("S,L,H,packed", [(301, 24, 12, False), (505, 24, 12, False), (410, 31, 12, True), (200, 20, 4, False), (420, 56, 12, True),
+                                          (130, 50, 3, False), (300, 22, 12, False)])
 def test_attention_several_pairs_per_wave(HF, Lb, S, L, H, packed):
     """Round 5: launches with more (sequence, head) pairs than one round of resident waves give every wave 2 or 3 pairs and
     prefetch the next pair's operands (attention_mfma.hip).  The arithmetic of a pair is unchanged: the big launch must give

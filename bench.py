@@ -317,6 +317,17 @@ def feed_run(device, rank, steps, warmup, n_batches=4):
                      "PCIe, copy stream one step ahead)" % n_batches}
 
 
+def _forget_previous_models():
+    """Between the workloads of one process: the package caches compute copies of the weights per parameter object (and refreshes
+    ALL of them after every optimiser step) and memoises tensors derived from batches - a later workload must not pay for, or
+    keep alive, its predecessors' models and batches (round 4's secondary.feed ran with the copies of four dead models)."""
+    import gc
+    from hero_amd import functional as HF_
+    HF_.reset_caches()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def box_probe(device):
     """What THIS box delivers right now (the same tree ran 6.37-7.49 ms per step on different boxes of the
     pool): ~0.2 s of back-to-back bf16 MFMAs on every CU (hero_probe_mfma: dense TFLOP/s, sustained matrix clock) and a
@@ -670,7 +681,7 @@ def main():
     # ---- N = 1: the other configurations ride on the line (short runs, after everything that is timed above) -------
     if rank == 0 and world == 1 and not dist_on and not args.no_secondary and not args.feed:
         del trainer, model, batch
-        torch.cuda.empty_cache()
+        _forget_previous_models()
         sec, t_sec = {}, time.perf_counter()
         ns = argparse.Namespace(**vars(args))
         for w in ("D2r", "D3", "D4"):
@@ -688,7 +699,7 @@ def main():
                 sec[w]["launch"] = r["config"]["launch"]
             except Exception as e:                       # noqa: BLE001 - a secondary line never takes the headline down
                 sec[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-            torch.cuda.empty_cache()
+            _forget_previous_models()
         try:
             sec["feed"] = feed_run(device, rank, steps=12, warmup=4)
         except Exception as e:                           # noqa: BLE001

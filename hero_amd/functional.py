@@ -860,14 +860,61 @@ def memo(tag, tensors, fn, extra=(), spec=None):
     return out
 
 
-def refresh_memo(sources=None):
+def reset_caches():
+    """Forget everything this module caches about models and batches that are no longer in use: compute copies of weights
+    (they keep their parameters - whole models - alive, and refresh_weight_cache() re-derives ALL of them after every
+    optimiser step), memoised batch tensors, workspaces, weight-gradient plans, the gradient sink.  For processes that build
+    several models in a row (bench.py's secondary workloads: each would otherwise pay for its predecessors' copies).
+    Not while a captured hipGraph that references those buffers is still going to be replayed."""
+    clear_weight_cache()
+    _MEMO.clear()
+    _WS.clear()
+    _WPLANS.clear()
+    _WPLANS_PINNED.clear()
+    _SEQ_OFF.clear()
+    _SLACK.clear()
+    del _WQ[:]
+    del _CQ[:]
+    set_grad_sink(None)
+
+
+def host_sortable_orders(batch):
+    """The memoised segment orders (`segment_order`: rows sorted by destination for the embedding-table gradients) that are a
+    function of ONE int64 id tensor of `batch`: [(batch key, order tensor, skip index)].  A feeder that gets its ids from the
+    host can compute such an order there (numpy stable argsort, hidden behind the GPU's step) and copy it in, instead of
+    re-sorting on the device inside every commit (hero_segment_sort is one workgroup: 69 us for 9600 ids)."""
+    by_out = {id(v[0]): v for v in _MEMO.values() if isinstance(v[0], torch.Tensor)}
+    keys = {t.data_ptr(): k for k, t in batch.items() if torch.is_tensor(t) and t.dtype == torch.int64}
+    found = []
+    for mk, (out, srcs, fn, spec) in _MEMO.items():
+        if mk[0] != "seg_order" or len(srcs) != 1:
+            continue
+        ridx = by_out.get(id(srcs[0]))                         # the int32 row index the order was sorted from ...
+        if ridx is None or len(ridx[1]) != 1:
+            continue
+        ids = ridx[1][0]                                       # ... itself derived from this int64 tensor
+        k = keys.get(ids.data_ptr())
+        if k is not None and batch[k].numel() == out.numel():
+            found.append((k, out, int(mk[1][1])))
+    return found
+
+
+def host_segment_order(ids, skip):
+    """numpy twin of hero_segment_sort: row numbers sorted by (id, row), rows with id < 0 or == skip last (stable)."""
+    v = np.asarray(ids, dtype=np.int64).reshape(-1)
+    key = np.where((v < 0) | (v == skip), np.int64(1) << 40, v)
+    return np.argsort(key, kind="stable").astype(np.int32)
+
+
+def refresh_memo(sources=None, skip_outputs=()):
     """Recompute memoised derived tensors IN PLACE from the current contents of their sources.  For callers that
     rewrite batch buffers in place (hero_amd.collate.DeviceCollate, or new data copied into a captured batch):
     captured graphs and cached maps hold the derived tensors by address.  sources: only the entries derived from one
     of these tensors (default: every entry).  Entries with a `spec` go out together as hero_derive_multi launches."""
     ptrs = None if sources is None else {t.data_ptr() for t in sources}
     batch, later = [], []
-    entries = list(_MEMO.values())
+    skip_ids = {id(t) for t in skip_outputs}                  # entries the caller refreshes itself (host-computed orders)
+    entries = [e for e in _MEMO.values() if id(e[0]) not in skip_ids]
     # entries a hero_derive_multi launch computes (functions of ONE raw int64 batch tensor) first, then the entries with a
     # builder of their own, which may be derived from those (segment_order sorts int32 row indices that are themselves
     # derived from the batch's ids): a refreshed entry's output counts as a source for the entries behind it

@@ -180,6 +180,9 @@ class StaticBatchFeeder:
         self._fill = 0            # staging set the next prefetch writes
         self._ready = []          # staging sets that hold a prefetched, not yet committed batch (FIFO)
         self._graph = [None, None]
+        self._orders = []         # (batch key, device order tensor, skip index): segment orders computed on the HOST (capture())
+        self.stage_order = [{}, {}]
+        self._order_ok = [False, False]
         self._versioned = None
         self._want_graph = capture_commit
         self.prefetch(host_batch)
@@ -215,6 +218,14 @@ class StaticBatchFeeder:
                 if src.numel() < dst.numel():
                     dst.zero_()
                 dst[:src.numel()].copy_(src, non_blocking=True)
+            # Segment orders of the id tensors (embedding-gradient scatter): a stable argsort of <= 10 k ids is ~0.3 ms of numpy
+            # on a host that has ~6 ms of slack per step; on the device it was a one-workgroup radix sort inside every commit
+            # (69 + 20 us of the commit graph's 239: tools/lab/feedprobe.py).
+            for k, _, skip in self._orders:
+                o = torch.from_numpy(HF.host_segment_order(host_batch[k].numpy(), skip))
+                self._pin_order[s][k].copy_(o)
+                self.stage_order[s][k].copy_(self._pin_order[s][k], non_blocking=True)
+            self._order_ok[s] = bool(self._orders)
             self._landed[s].record(self.copy_stream)
 
     def _commit_body(self, s):
@@ -222,7 +233,9 @@ class StaticBatchFeeder:
             self.static[k].copy_(self.stage[s][k])
         self.dc.load_lengths(self.stage_len[s], src_device=True)
         self.dc.rebuild(c_v_feats=self.static["c_v_feats"])
-        HF.refresh_memo([t for t in self.static.values() if torch.is_tensor(t)])
+        for k, out, _ in self._orders:                       # host-sorted orders: copied in, not re-sorted
+            out.copy_(self.stage_order[s][k])
+        HF.refresh_memo([t for t in self.static.values() if torch.is_tensor(t)], skip_outputs=[o for _, o, _ in self._orders])
 
     def commit(self):
         """Make the oldest prefetched batch the current one: on the compute stream, staging -> static buffers, then
@@ -233,6 +246,8 @@ class StaticBatchFeeder:
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(self._landed[s])
         if self._graph[s] is not None:
+            if self._orders and not self._order_ok[s]:
+                raise RuntimeError("StaticBatchFeeder: this batch was prefetched before capture(); prefetch after capture()")
             self._graph[s].replay()
             # a replay does not move the version counters the eager-mode caches (functional.memo) key on
             torch._C._increment_version(self._versioned)       # takes an ITERABLE of tensors (a bare tensor is iterated row by row)
@@ -247,7 +262,16 @@ class StaticBatchFeeder:
         ~40 small ones."""
         if not self._want_graph or self._graph[0] is not None:
             return
+        if self._ready:
+            raise RuntimeError("StaticBatchFeeder.capture: commit() the prefetched batch first (orders are computed on the host from now on)")
         torch.cuda.synchronize(self.device)
+        # the step has run on self.static: its segment orders exist - take over the ones that depend on host ids only
+        self._orders = HF.host_sortable_orders(self.static)
+        self.stage_order = [{k: torch.empty_like(o) for k, o, _ in self._orders} for _ in range(2)]
+        self._pin_order = [{k: torch.empty(o.shape, dtype=o.dtype).pin_memory() for k, o, _ in self._orders} for _ in range(2)]
+        for s_ in range(2):                                  # valid contents for the capture run itself
+            for k, o, _ in self._orders:
+                self.stage_order[s_][k].copy_(o)
         for s in range(2):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

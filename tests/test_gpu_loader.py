@@ -137,3 +137,19 @@ def test_prefetch_loader_over_meta_loader_moves_the_whole_batch():
         if seen == 5:
             break
     assert seen == 5
+
+
+def test_host_segment_order_is_the_device_sort():
+    """StaticBatchFeeder sorts the token ids of the NEXT batch on the host (numpy stable argsort) instead of re-sorting on the
+    device inside every commit: same order as hero_segment_sort (rows by (id, row), padding / negative ids last)."""
+    from hero_amd import functional as HF
+    g = torch.Generator().manual_seed(5)
+    for n, vocab, skip in ((9600, 50272, 1), (480, 50272, 1), (777, 13, -1), (5, 3, 0)):
+        ids = torch.randint(0, vocab, (n,), generator=g)
+        ids[::7] = 2                                     # a run that spans many blocks (the SEP token)
+        if skip >= 0:
+            ids[3::11] = skip
+        idx = ids.to(torch.int32).cuda()
+        dev = HF.segment_order(idx, vocab, skip)
+        host = torch.from_numpy(HF.host_segment_order(ids.numpy(), skip))
+        assert torch.equal(dev.cpu(), host), (n, vocab, skip)

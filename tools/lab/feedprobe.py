@@ -29,7 +29,7 @@ print("prefetch+commit  %.3f ms" % T(c1))
 
 fd.prefetch(host[0])
 def full(i):
-    b = fd.commit(); fd.prefetch(host[(i + 1) % 4]); tr.micro_step(b)
+    b = fd.commit(); tr.micro_step(b); fd.prefetch(host[(i + 1) % 4])
 print("commit+prefetch+step %.3f ms" % T(full))
 fd.commit()
 # pieces of the commit (eager, GPU time by events)

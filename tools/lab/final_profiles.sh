@@ -27,5 +27,6 @@ for w in D2r D3 D4; do
   timeout 400 python bench.py --workload $w --no-cpu-baseline 2> $OUT/${TAG}_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 timeout 300 python bench.py --workload D2r --no-graph --no-cpu-baseline 2>> $OUT/${TAG}_D2r.err | tail -1 > $OUT/${TAG}_bench_D2r_eager.json
-tail -3 $OUT/${TAG}_run.log; cut -c1-200 $OUT/${TAG}_bench.json; cut -c1-200 $OUT/${TAG}_bench_feed.json
+(timeout 300 python tools/lab/feedprobe.py 2>&1 | grep -v Warning | tail -22) > $OUT/${TAG}_feedprobe.txt
+tail -3 $OUT/${TAG}_run.log; cat $OUT/${TAG}_feedprobe.txt; cut -c1-200 $OUT/${TAG}_bench.json; cut -c1-200 $OUT/${TAG}_bench_feed.json
 for w in D2r D3 D4; do head -8 $OUT/${TAG}_kernel_stats_$w.csv | cut -c1-140; done

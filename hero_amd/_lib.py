@@ -19,7 +19,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DG, ACT_MUL_A
 EXPORTS = [
     "hero_last_error", "hero_abi_version", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_probe_mfma", "hero_probe_hbm", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
-    "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok",
+    "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok", "hero_attention_force_ppw",
     "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
@@ -205,6 +205,7 @@ def lib():
         L.hero_attention_fwd.argtypes = [C.POINTER(Attn), C.c_void_p]
         L.hero_attention_bwd.argtypes = [C.POINTER(Attn), C.c_void_p]
         L.hero_attention_stats_ok.argtypes = [C.c_int, C.c_int]
+        L.hero_attention_force_ppw.argtypes = [C.c_int]
         L.hero_attention_max_len.argtypes = [C.c_int, C.c_int]
         L.hero_attention_max_packed_len.argtypes = [C.c_int]
         L.hero_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

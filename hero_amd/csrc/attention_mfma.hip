@@ -275,10 +275,16 @@ __global__ __launch_bounds__(64 * WPB, (PPW == 2 ? 3 : 1)) void attn_mfma_fwd_ke
   const PairCoord c0 = pair_coord<CLS>(a, wid), c1 = pair_coord<CLS>(a, PPW > 1 ? wid + nw : wid),
                   c2 = pair_coord<CLS>(a, PPW > 2 ? wid + 2 * nw : wid);
   FwdIn<NB> A, B;
+#ifdef HERO_ATTN_LATE_ISSUE          // lab (tools/lab/attn_ab.py): the next pair's loads are issued once this pair's have landed
+  constexpr bool LATE = true;
+#else
+  constexpr bool LATE = false;
+#endif
   fwd_issue<NB, M4>(a, c0, A, lane);
-  if (PPW > 1) fwd_issue<NB, M4>(a, c1, B, lane);                          // next pair's loads fly during this pair
+  if (PPW > 1 && !LATE) fwd_issue<NB, M4>(a, c1, B, lane);                 // next pair's loads fly during this pair
   fwd_stage<NB>(A, Vs, lane);
   wave_sync_lds();
+  if (PPW > 1 && LATE) fwd_issue<NB, M4>(a, c1, B, lane);
   if (A.on) fwd_compute<NB>(a, A, Vs, drop, lane);
   if (PPW > 1) {
     if (PPW > 2) fwd_issue<NB, M4>(a, c2, A, lane);
@@ -551,10 +557,16 @@ __global__ __launch_bounds__(64 * WPB, (PPW > 1 ? 2 : 1)) void attn_mfma_bwd_ker
   BwdIn<NB> A, B;
   bf16_t* Qs = Ks + R * RS;
   bf16_t* Os = Qs + R * RS;
+#ifdef HERO_ATTN_LATE_ISSUE
+  constexpr bool LATE = true;
+#else
+  constexpr bool LATE = false;
+#endif
   bwd_issue<NB, RC, M4>(a, c0, A, lane);
-  if (PPW > 1) bwd_issue<NB, RC, M4>(a, c1, B, lane);                      // next pair's loads fly during this pair
+  if (PPW > 1 && !LATE) bwd_issue<NB, RC, M4>(a, c1, B, lane);             // next pair's loads fly during this pair
   bwd_stage<NB>(A, Ks, Qs, Os, lane);
   wave_sync_lds();
+  if (PPW > 1 && LATE) bwd_issue<NB, RC, M4>(a, c1, B, lane);
   if (A.on) bwd_compute<NB, RC>(a, A, Ks, drop, lane);
   if (PPW > 1) {
     if (PPW > 2) bwd_issue<NB, RC, M4>(a, c2, A, lane);
@@ -953,12 +965,15 @@ int launch_ppw(const HeroAttn& a, bool bwd, hipStream_t s) {
 // Pairs per wave: as many as make the launch ONE round of resident waves - forward 12 per CU (the two-pair kernel holds 152
 // registers: three waves per SIMD), backward 8 per CU (two per SIMD: <= 256 registers, and its 19 KB of LDS tiles per wave
 // allow no more) - at most 3; small launches keep one pair per wave.  The bench batch: 6144 pairs = 2 x 3072 = 3 x 2048.
+static int g_force_ppw = 0;          // hero_attention_force_ppw: 0 = heuristic, 1..3 = pairs per wave (tuning hook / tests)
+
 template <int WPB, int CLS, bool M4>
 int launch_m(const HeroAttn& a, bool bwd, hipStream_t s) {
   const long slots = (long)cu_count() * (bwd ? 8 : 12);
   const long pairs = (long)a.S * a.H;
-  if (pairs > 2 * slots) return launch_ppw<1, WPB, CLS, 3, M4>(a, bwd, s);
-  if (pairs > slots) return launch_ppw<1, WPB, CLS, 2, M4>(a, bwd, s);
+  const int ppw = g_force_ppw ? g_force_ppw : (pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1));
+  if (ppw == 3) return launch_ppw<1, WPB, CLS, 3, M4>(a, bwd, s);
+  if (ppw == 2) return launch_ppw<1, WPB, CLS, 2, M4>(a, bwd, s);
   return launch_ppw<1, WPB, CLS, 1, M4>(a, bwd, s);
 }
 template <int WPB, int CLS>
@@ -979,3 +994,10 @@ int attn_mfma_run(const HeroAttn& a, bool bwd, hipStream_t s) {
 }
 
 }  // namespace hero
+
+// Tuning hook (like hero_gemm_force_config): pairs per wave of the L <= 32 matrix-core attention kernels; 0 = heuristic.
+extern "C" int hero_attention_force_ppw(int ppw) {
+  if (ppw < 0 || ppw > 3) { hero::set_error("hero_attention_force_ppw: 0 (heuristic) .. 3"); return HERO_ERR_ARG; }
+  hero::g_force_ppw = ppw;
+  return HERO_OK;
+}

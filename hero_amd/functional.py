@@ -883,13 +883,13 @@ def host_sortable_orders(batch):
     function of ONE int64 id tensor of `batch`: [(batch key, order tensor, skip index)].  A feeder that gets its ids from the
     host can compute such an order there (numpy stable argsort, hidden behind the GPU's step) and copy it in, instead of
     re-sorting on the device inside every commit (hero_segment_sort is one workgroup: 69 us for 9600 ids)."""
-    by_out = {id(v[0]): v for v in _MEMO.values() if isinstance(v[0], torch.Tensor)}
+    by_out = {v[0].data_ptr(): v for v in _MEMO.values() if isinstance(v[0], torch.Tensor)}      # by address: callers pass views (idx.view(-1))
     keys = {t.data_ptr(): k for k, t in batch.items() if torch.is_tensor(t) and t.dtype == torch.int64}
     found = []
     for mk, (out, srcs, fn, spec) in _MEMO.items():
         if mk[0] != "seg_order" or len(srcs) != 1:
             continue
-        ridx = by_out.get(id(srcs[0]))                         # the int32 row index the order was sorted from ...
+        ridx = by_out.get(srcs[0].data_ptr())                  # the int32 row index the order was sorted from ...
         if ridx is None or len(ridx[1]) != 1:
             continue
         ids = ridx[1][0]                                       # ... itself derived from this int64 tensor

@@ -270,6 +270,7 @@ int hero_attention_max_len(int dtype, int backward);
 /* longest sequence of a PACKED (seq_off) batch the kernels take for this dtype: 256 on the bf16 matrix-core */
 /* kernels, 64 otherwise (fp32, or HERO_ATTN_MFMA=0) - callers fall back to the padded layout beyond it      */
 int hero_attention_max_packed_len(int dtype);
+int hero_attention_force_ppw(int ppw); /* tuning hook: (sequence, head) pairs per wave of the L <= 32 bf16 kernels, 1..3; 0 = heuristic */
 /* 1 when forward + backward of this dtype / length run from `stats` without saved probabilities (bf16 matrix-core */
 /* kernels, L <= 64)                                                                                               */
 int hero_attention_stats_ok(int dtype, int L);

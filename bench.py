@@ -344,11 +344,29 @@ def box_probe(device):
     L.check(L.lib().hero_probe_hbm(a.data_ptr(), b.data_ptr(), n, C.byref(cp), C.byref(rd), st))
     torch.cuda.synchronize()
     del a, b
+    # Third probe: the product GEMM itself on one shape of the step (12000 x 3072 x 768, no epilogue).  The round's boxes with
+    # EQUAL MFMA and HBM probes still ran the step 15 % apart (6.15 vs 7.26 ms): what differs between them is the path the
+    # persistent GEMM loop is bound by (L2 -> LDS fill), which neither pure probe exercises.
+    from hero_amd import functional as HF
+    x = torch.randn(12000, 768, device=device).to(torch.bfloat16)
+    w = (torch.randn(3072, 768, device=device) * 0.05).to(torch.bfloat16)
+    for _ in range(60):
+        HF.k_linear(x, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(40):
+        HF.k_linear(x, w)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_us = e0.elapsed_time(e1) * 1000 / 40
+    del x, w
     torch.cuda.empty_cache()
     return {"mfma_bf16_tflops": round(tf.value, 1), "mfma_clock_ghz": round(ghz.value, 3),
             "hbm_copy_gbps": round(cp.value, 1), "hbm_read_gbps": round(rd.value, 1),
+            "gemm_12000x3072x768_us": round(gemm_us, 1), "gemm_12000x3072x768_tflops": round(2.0 * 12000 * 3072 * 768 / gemm_us / 1e6, 1),
             "how": "hero_probe_mfma: 36 independent v_mfma_f32_32x32x16_bf16 per iteration on 8 waves x every CU, past the clock ramp; "
-                   "hero_probe_hbm: 1 GiB nontemporal streaming copy (read + written bytes) and read"}
+                   "hero_probe_hbm: 1 GiB nontemporal streaming copy (read + written bytes) and read; gemm: 40 back-to-back hero_gemm launches "
+                   "(eager, HIP events)"}
 
 
 def launch_command(n, argv, n_devices, port=None):

@@ -962,16 +962,20 @@ int launch_ppw(const HeroAttn& a, bool bwd, hipStream_t s) {
   return check_launch(bwd ? "hero_attention_bwd(mfma)" : "hero_attention_fwd(mfma)");
 }
 
-// Pairs per wave: as many as make the launch ONE round of resident waves - forward 12 per CU (the two-pair kernel holds 152
-// registers: three waves per SIMD), backward 8 per CU (two per SIMD: <= 256 registers, and its 19 KB of LDS tiles per wave
-// allow no more) - at most 3; small launches keep one pair per wave.  The bench batch: 6144 pairs = 2 x 3072 = 3 x 2048.
+// Pairs per wave of the BACKWARD: as many as make the launch ONE round of resident waves - 8 per CU (two per SIMD: <= 256
+// registers, and its 19 KB of LDS tiles per wave allow no more) - at most 3; small launches keep one pair per wave.  The bench
+// batch: 6144 pairs = 3 x 2048.  The forward keeps one pair per wave (measurements below).
 static int g_force_ppw = 0;          // hero_attention_force_ppw: 0 = heuristic, 1..3 = pairs per wave (tuning hook / tests)
 
 template <int WPB, int CLS, bool M4>
 int launch_m(const HeroAttn& a, bool bwd, hipStream_t s) {
   const long slots = (long)cu_count() * (bwd ? 8 : 12);
   const long pairs = (long)a.S * a.H;
-  const int ppw = g_force_ppw ? g_force_ppw : (pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1));
+  // Measured on MI355X (tools/lab/attn_ab.py, the bench batch's 5760 pairs, hipGraph timing): backward 32.5 / 31.2 / 31.0 us
+  // with 1 / 2 / 3 pairs per wave (round 4: 35.7), forward 17.6 / 18.6 / 18.7 (round 4: 17.9) - the forward's pairs are short
+  // enough that a second round of independently scheduled waves overlaps loads and compute better than a wave's own
+  // prefetch does, so it keeps one pair per wave; the hook can still force 2 or 3.
+  const int ppw = g_force_ppw ? g_force_ppw : (!bwd ? 1 : (pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1)));
   if (ppw == 3) return launch_ppw<1, WPB, CLS, 3, M4>(a, bwd, s);
   if (ppw == 2) return launch_ppw<1, WPB, CLS, 2, M4>(a, bwd, s);
   return launch_ppw<1, WPB, CLS, 1, M4>(a, bwd, s);

@@ -756,7 +756,7 @@ def test_attention_packed_sequences(HF, dtype, lens, H):
 def test_attention_several_pairs_per_wave(HF, Lb, S, L, H, packed):
     """Round 5: launches with more (sequence, head) pairs than one round of resident waves give every wave 2 or 3 pairs and
     prefetch the next pair's operands (attention_mfma.hip).  The arithmetic of a pair is unchanged: the big launch must give
-    the BITS of the same sequences run in launches of other sizes (other wave <-> pair assignments), forward and backward, with dropout, with the
+    the BITS of the same sequences run one pair per wave in launches of other sizes (hero_attention_force_ppw), forward and backward, with dropout, with the
     saved row statistics and with saved probabilities, padded and packed (ragged lengths, incl. pairs past the last wave)."""
     D = H * 64
     dtype = torch.bfloat16
@@ -769,11 +769,15 @@ def test_attention_several_pairs_per_wave(HF, Lb, S, L, H, packed):
     m[:, 0] = 1
     madd = ((1 - m) * -10000.0).cuda()
     drop = HF.RNG.make(0.1, True, qkv.device)
-    for save_probs in (False, True):
+    for save_probs, ppw in ((False, 0), (True, 0), (False, 2), (False, 3), (True, 3)):
         HF.ATTN_SAVE_PROBS = save_probs
         try:
-            ctx, saved = HF.k_attn_fwd(qkv, madd, S, L, H, drop=drop, seq_off=off)
-            dq = HF.k_attn_bwd(qkv, saved, dctx, S, L, H, drop=drop, seq_off=off, ctx=ctx, mask_add=madd)
+            Lb.check(Lb.lib().hero_attention_force_ppw(ppw))     # 0: the launcher's choice; 2 / 3 pairs per wave, forward and backward
+            try:
+                ctx, saved = HF.k_attn_fwd(qkv, madd, S, L, H, drop=drop, seq_off=off)
+                dq = HF.k_attn_bwd(qkv, saved, dctx, S, L, H, drop=drop, seq_off=off, ctx=ctx, mask_add=madd)
+            finally:
+                Lb.check(Lb.lib().hero_attention_force_ppw(1))   # the reference launches below: one pair per wave
             # the same sequences in chunks of 64 - the dropout index of an element depends on
             # its sequence number, so every chunk is run as sequences [s0, s0 + n) of a launch of s0 + n sequences whose first s0 are
             # empty (packed form: seq_off = 0 ... 0, then the chunk's bounds)
@@ -787,11 +791,12 @@ def test_attention_several_pairs_per_wave(HF, Lb, S, L, H, packed):
                 c1, sv1 = HF.k_attn_fwd(qkv[r0:r0 + rows].contiguous(), mk, s0 + n, L, H, drop=drop, seq_off=o)
                 d1 = HF.k_attn_bwd(qkv[r0:r0 + rows].contiguous(), sv1, dctx[r0:r0 + rows].contiguous(), s0 + n, L, H, drop=drop, seq_off=o,
                                    ctx=c1, mask_add=mk)
-                assert torch.equal(ctx[r0:r0 + rows], c1), (save_probs, s0)
-                assert torch.equal(dq[r0:r0 + rows], d1), (save_probs, s0)
+                assert torch.equal(ctx[r0:r0 + rows], c1), (save_probs, ppw, s0)
+                assert torch.equal(dq[r0:r0 + rows], d1), (save_probs, ppw, s0)
                 r0 += rows
         finally:
             HF.ATTN_SAVE_PROBS = False
+            Lb.check(Lb.lib().hero_attention_force_ppw(0))
     # and against fp32 torch (padded case only: one reference for the whole launch)
     if not packed:
         ctx, saved = HF.k_attn_fwd(qkv, madd, S, L, H)

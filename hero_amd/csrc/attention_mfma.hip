@@ -975,7 +975,10 @@ int launch_m(const HeroAttn& a, bool bwd, hipStream_t s) {
   // with 1 / 2 / 3 pairs per wave (round 4: 35.7), forward 17.6 / 18.6 / 18.7 (round 4: 17.9) - the forward's pairs are short
   // enough that a second round of independently scheduled waves overlaps loads and compute better than a wave's own
   // prefetch does, so it keeps one pair per wave; the hook can still force 2 or 3.
-  const int ppw = g_force_ppw ? g_force_ppw : (!bwd ? 1 : (pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1)));
+  // Length-class launches of a packed batch (CLS != 0) own only some of the pairs they walk: with several pairs per wave the
+  // waves that drew two or three owned pairs become the tail (ragged TVR batch, backward: 47 us with three pairs per wave on a
+  // box where one pair per wave took ~40) - they keep one pair per wave as well.
+  const int ppw = g_force_ppw ? g_force_ppw : ((!bwd || CLS != 0) ? 1 : (pairs > 2 * slots ? 3 : (pairs > slots ? 2 : 1)));
   if (ppw == 3) return launch_ppw<1, WPB, CLS, 3, M4>(a, bwd, s);
   if (ppw == 2) return launch_ppw<1, WPB, CLS, 2, M4>(a, bwd, s);
   return launch_ppw<1, WPB, CLS, 1, M4>(a, bwd, s);

@@ -20,10 +20,10 @@ EXPORTS = [
     "hero_last_error", "hero_abi_version", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_probe_mfma", "hero_probe_hbm", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok", "hero_attention_force_ppw",
-    "hero_gather_rows", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
+    "hero_gather_rows", "hero_inverse_first", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
     "hero_relu_bwd", "hero_gelu_bwd", "hero_add", "hero_sumsq", "hero_adamw", "hero_adamw_multi", "hero_adamw_multi_chunk",
     "hero_query_pool_fwd", "hero_query_pool_bwd", "hero_rownorm_fwd", "hero_rownorm_bwd", "hero_score_max_fwd",
-    "hero_score_max_bwd", "hero_rank_loss", "hero_st_ed_fwd", "hero_st_ed_bwd", "hero_st_ed_bwd_workspace_bytes",
+    "hero_score_max_bwd", "hero_rank_loss", "hero_sums_scaled", "hero_st_ed_fwd", "hero_st_ed_bwd", "hero_st_ed_bwd_workspace_bytes",
     "hero_cross_entropy_fwd", "hero_cross_entropy_bwd",
     "hero_collate_subs", "hero_collate_clip_mask", "hero_collate_frame_map", "hero_collate_gather_feats", "hero_derive_multi",
     "hero_comm_available", "hero_comm_unique_id", "hero_comm_init", "hero_comm_destroy", "hero_comm_rank", "hero_comm_world",
@@ -137,7 +137,7 @@ class ScoreMax(C.Structure):
                 ("ds_ctx", C.c_void_p), ("ds_q", C.c_void_p), ("gc", C.c_void_p), ("gq", C.c_void_p),
                 ("qn", C.c_void_p), ("cn", C.c_void_p), ("dqn", C.c_void_p), ("dcn", C.c_void_p),
                 ("M", C.c_int), ("N", C.c_int), ("L", C.c_int), ("D", C.c_int), ("n0", C.c_int),
-                ("n_own", C.c_int), ("ld_s", C.c_int)]
+                ("n_own", C.c_int), ("ld_s", C.c_int), ("gc_scale", C.c_float), ("gq_scale", C.c_float)]
 
 
 class RankLoss(C.Structure):
@@ -152,7 +152,7 @@ class StEd(C.Structure):
                 ("w_ed", C.c_void_p), ("targets", C.c_void_p), ("loss_rows", C.c_void_p),
                 ("p_st", C.c_void_p), ("p_ed", C.c_void_p), ("sim", C.c_void_p), ("g", C.c_void_p),
                 ("dq2", C.c_void_p), ("dctx", C.c_void_p), ("dw_st", C.c_void_p), ("dw_ed", C.c_void_p),
-                ("B", C.c_int), ("L", C.c_int), ("D", C.c_int), ("K", C.c_int), ("dtype", C.c_int), ("pad_", C.c_int),
+                ("B", C.c_int), ("L", C.c_int), ("D", C.c_int), ("K", C.c_int), ("dtype", C.c_int), ("g_scale", C.c_float),
                 ("ws", C.c_void_p)]
 
 
@@ -210,6 +210,7 @@ def lib():
         L.hero_attention_max_packed_len.argtypes = [C.c_int]
         L.hero_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.hero_inverse_first.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.hero_csr_gather_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.hero_scatter_add_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -239,6 +240,7 @@ def lib():
                        ("hero_score_max_fwd", ScoreMax), ("hero_score_max_bwd", ScoreMax),
                        ("hero_rank_loss", RankLoss), ("hero_st_ed_fwd", StEd), ("hero_st_ed_bwd", StEd)):
             getattr(L, fn).argtypes = [C.POINTER(st), C.c_void_p]
+        L.hero_sums_scaled.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         L.hero_collate_subs.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]
         L.hero_collate_gather_feats.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
         L.hero_derive_multi.argtypes = [C.POINTER(Derive), C.c_int, C.c_void_p]

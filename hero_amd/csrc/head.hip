@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void score_max_fwd_kernel(HeroScoreMax a) {
 // dqn: one workgroup per query m
 __global__ __launch_bounds__(256) void score_max_bwd_q_kernel(HeroScoreMax a) {
   const int m = blockIdx.x;
-  const float gc = a.gc[0], gq = a.gq[0];
+  const float gc = a.gc[0] * (a.gc_scale != 0.f ? a.gc_scale : 1.f), gq = a.gq[0] * (a.gq_scale != 0.f ? a.gq_scale : 1.f);
   for (int d = threadIdx.x * 4; d < a.D; d += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int n = 0; n < a.N; ++n) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void score_max_bwd_c_kernel(HeroScoreMax a) {
   float* out = a.dcn + (size_t)nl * a.L * a.D;
   for (size_t i = threadIdx.x * 4; i < (size_t)a.L * a.D; i += 1024) *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const float gc = a.gc[0], gq = a.gq[0];
+  const float gc = a.gc[0] * (a.gc_scale != 0.f ? a.gc_scale : 1.f), gq = a.gq[0] * (a.gq_scale != 0.f ? a.gq_scale : 1.f);
   // each thread owns its columns in every row of this video: plain read-modify-write, fixed order
   for (int d = threadIdx.x * 4; d < a.D; d += 1024) {
     for (int m = 0; m < a.M; ++m) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
   }
   c0 = block_sum(c0, red);
   c1 = block_sum(c1, red);
-  const float g = a.g[0];
+  const float g = a.g[0] * (a.g_scale != 0.f ? a.g_scale : 1.f);
   for (int i = threadIdx.x; i < 2 * a.L; i += 256) {  // d logits (through mask_logits)
     const int which = i / a.L, l = i - which * a.L;
     const long long t = a.targets[2 * b + which];
@@ -433,6 +433,19 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
 }
 
 }  // namespace
+// out[s] = scale[s] * sum(src[s * seg_len .. (s + 1) * seg_len)) for up to 4 segments: the final reductions of the loss head
+// (sum of the start / end rows, means of the two ranking-loss rows) with their loss weights folded in - one wave per segment,
+// fixed summation order (lane-strided partial sums, then the DPP wave sum): bit-reproducible.
+struct SumsArgs { const float* src; float* out; int n_segs, seg_len; float scale[4]; };
+__global__ __launch_bounds__(64) void sums_scaled_kernel(SumsArgs a) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const float* p = a.src + (size_t)s * a.seg_len;
+  float v = 0.f;
+  for (int i = lane; i < a.seg_len; i += 64) v += p[i];
+  v = wave_sum(v);
+  if (lane == 0) a.out[s] = v * a.scale[s];
+}
+
 }  // namespace hero
 
 using namespace hero;
@@ -524,4 +537,13 @@ extern "C" int hero_st_ed_bwd(const HeroStEd* a, hero_stream_t stream) {
   HERO_REQUIRE(a->ws || !(a->dw_st || a->dw_ed), "hero_st_ed_bwd: dw_st / dw_ed need the workspace (hero_st_ed_bwd_workspace_bytes)");
   if (a->B <= 0) return HERO_OK;
   HERO_BY_DTYPE(a->dtype, st_ed_bwd_kernel, a->B, 4 * a->L * sizeof(float), static_cast<hipStream_t>(stream), *a, "hero_st_ed_bwd");
+}
+
+extern "C" int hero_sums_scaled(const float* src, int n_segs, int seg_len, const float* scales, float* out, hero_stream_t stream) {
+  HERO_REQUIRE(src && out && scales && n_segs >= 1 && n_segs <= 4 && seg_len >= 1, "hero_sums_scaled: 1..4 segments of >= 1 element");
+  SumsArgs a;
+  a.src = src; a.out = out; a.n_segs = n_segs; a.seg_len = seg_len;
+  for (int i = 0; i < 4; ++i) a.scale[i] = i < n_segs ? scales[i] : 0.f;
+  hipLaunchKernelGGL(sums_scaled_kernel, dim3(n_segs), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  return check_launch("hero_sums_scaled");
 }

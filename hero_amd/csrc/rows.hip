@@ -18,6 +18,23 @@ __global__ void gather_rows_kernel(const T* __restrict__ a, const T* __restrict_
   }
 }
 
+// ---- first occurrence of every source row in a gather index ----------------------------------------
+// inv[r] (a rows) / inv[na + r] (b rows) = the smallest output row j whose idx[j] names that source row, -1 if none.  One
+// workgroup, the whole table in LDS (atomicMin is order-independent: deterministic).
+__global__ __launch_bounds__(1024) void inverse_first_kernel(const int32_t* __restrict__ idx, int n, int32_t* __restrict__ inv, int na, int nb) {
+  extern __shared__ int lds_inv[];
+  const int tot = na + nb;
+  for (int i = threadIdx.x; i < tot; i += 1024) lds_inv[i] = 0x7fffffff;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 1024) {
+    const int v = idx[j];
+    if (v >= 0 && v < na) atomicMin(&lds_inv[v], j);
+    else if (v <= -2 && -v - 2 < nb) atomicMin(&lds_inv[na - v - 2], j);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tot; i += 1024) { const int v = lds_inv[i]; inv[i] = v == 0x7fffffff ? -1 : v; }
+}
+
 // ---- out[r] = sum over CSR entries ---------------------------------------------------------------
 template <typename T>
 __global__ void csr_gather_sum_kernel(const T* __restrict__ src, const int32_t* __restrict__ offs,
@@ -575,6 +592,16 @@ extern "C" int hero_gather_rows(const void* a, const void* b, const int32_t* idx
     hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, idx, (bf16_t*)out, rows, cols);
   else { set_error("hero_gather_rows: bad dtype %d", dtype); return HERO_ERR_ARG; }
   return check_launch("hero_gather_rows");
+}
+
+extern "C" int hero_inverse_first(const int32_t* idx, int n, int32_t* inv, int na, int nb, hero_stream_t stream) {
+  HERO_REQUIRE(idx && inv && n >= 0 && na >= 0 && nb >= 0, "hero_inverse_first: bad arguments");
+  if (na + nb == 0) return HERO_OK;
+  const size_t lds = (size_t)(na + nb) * sizeof(int);
+  if (lds > 150 * 1024) { set_error("hero_inverse_first: %d source rows exceed the LDS-resident table (38400)", na + nb); return HERO_ERR_UNSUPPORTED; }
+  if (lds > 65536) HERO_ENSURE_LDS(&inverse_first_kernel, 150 * 1024, "inverse_first_kernel");
+  hipLaunchKernelGGL(inverse_first_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), idx, n, inv, na, nb);
+  return check_launch("hero_inverse_first");
 }
 
 extern "C" int hero_csr_gather_sum(const void* src, const int32_t* offsets, const int32_t* entries, void* out, int rows,

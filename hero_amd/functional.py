@@ -1244,20 +1244,43 @@ class GatherRowsFn(torch.autograd.Function):
     """out[r] = a[idx[r]] (idx>=0) | 0 (idx==-1) | b[-idx-2]."""
 
     @staticmethod
-    def forward(ctx, a, b, idx, tail_rows=0):
+    def forward(ctx, a, b, idx, tail_rows=0, first_grad=False):
+        """first_grad: the caller guarantees that a source row referenced more than once receives gradient through its FIRST
+        reference only (HERO's f_gather_index: the later references are padded positions, whose gradients are exactly zero) -
+        the backward is then one gather through the first-occurrence map (hero_inverse_first) instead of two zero fills and a
+        scatter-add."""
         a2, b2 = _as2d(a), (_as2d(b) if b is not None else None)
         ctx.save_for_backward(idx)
         ctx.ashape, ctx.bshape = a.shape, (b.shape if b is not None else None)
+        na, nb = a2.shape[0], (b2.shape[0] if b2 is not None else 0)
+        ctx.first = bool(first_grad) and na + nb <= 38400 and idx.dtype == torch.int32 and idx.is_contiguous()
         return k_gather_rows(a2, b2, idx, idx.numel(), a2.shape[1], tail_rows=tail_rows)
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         dy2 = _as2d(dy)
+        if ctx.first:
+            na = 1
+            for d_ in ctx.ashape[:-1]:
+                na *= int(d_)
+            nb = 0
+            if ctx.bshape is not None:
+                nb = 1
+                for d_ in ctx.bshape[:-1]:
+                    nb *= int(d_)
+
+            def build():
+                inv = torch.empty(na + nb, dtype=torch.int32, device=idx.device)
+                L.check(L.lib().hero_inverse_first(L.ptr(idx), idx.numel(), L.ptr(inv), na, nb, L.stream()))
+                return inv
+            inv = memo("gather_inverse", (idx,), build, (na, nb))
+            both = k_gather_rows(dy2.contiguous(), None, inv, na + nb, dy2.shape[1])
+            return both[:na].view(ctx.ashape), (both[na:].view(ctx.bshape) if ctx.bshape is not None else None), None, None, None
         da = torch.zeros(ctx.ashape, dtype=dy.dtype, device=dy.device)
         db = torch.zeros(ctx.bshape, dtype=dy.dtype, device=dy.device) if ctx.bshape is not None else None
         k_scatter_add(dy2, idx, da, db)
-        return da, db, None, None
+        return da, db, None, None, None
 
 
 class PermuteRowsFn(torch.autograd.Function):

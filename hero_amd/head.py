@@ -94,7 +94,9 @@ class VideoRankLossFn(torch.autograd.Function):
     the gather's backward anyway, model/pretrain.py:442-447)."""
 
     @staticmethod
-    def forward(ctx, qn, cn, mask, own, margin, lse, hard, pool, hard_w):
+    def forward(ctx, qn, cn, mask, own, margin, lse, hard, pool, hard_w, w_ctx=1.0, w_q=1.0):
+        """w_ctx / w_q: the loss weights (model/pretrain.py:283-290), folded into the final reductions and into the backward
+        kernels' upstream-gradient scalars - the returned losses are already weighted."""
         M, D = qn.shape
         N, Lc, _ = cn.shape
         qn, cn, mask = _f32c(qn), _f32c(cn), _f32c(mask)
@@ -121,7 +123,9 @@ class VideoRankLossFn(torch.autograd.Function):
         L.check(L.lib().hero_rank_loss(C.byref(r), L.stream()))
         ctx.save_for_backward(qn, cn, mask, arg, ds)
         ctx.own = own
-        both = rows.mean(1)
+        ctx.w = (float(w_ctx), float(w_q))
+        both = torch.empty((2,), dtype=torch.float32, device=dev)
+        L.check(L.lib().hero_sums_scaled(L.ptr(rows), 2, M, (C.c_float * 2)(float(w_ctx) / M, float(w_q) / M), L.ptr(both), L.stream()))
         return both[0], both[1]
 
     @staticmethod
@@ -131,18 +135,19 @@ class VideoRankLossFn(torch.autograd.Function):
         N, Lc, _ = cn.shape
         n0, n_own = ctx.own
         dev = qn.device
-        g = torch.stack([g_ctx.reshape(()), g_q.reshape(())]).to(torch.float32).contiguous()
+        g_ctx, g_q = _f32c(g_ctx).reshape(1), _f32c(g_q).reshape(1)      # two device scalars, read where they are (no stack)
         dqn = torch.empty_like(qn)
         full = n0 == 0 and n_own == N
         dcn = (torch.empty if full else torch.zeros)((N, Lc, D), dtype=torch.float32, device=dev)
         a = L.ScoreMax()
         a.mask, a.arg, a.ds_ctx, a.ds_q = L.ptr(mask), L.ptr(arg), L.ptr(ds[0]), L.ptr(ds[1])
-        a.gc, a.gq = g.data_ptr(), g.data_ptr() + 4
+        a.gc, a.gq = L.ptr(g_ctx), L.ptr(g_q)
+        a.gc_scale, a.gq_scale = ctx.w
         a.qn, a.cn, a.dqn = L.ptr(qn), L.ptr(cn), L.ptr(dqn)
         a.dcn = dcn.data_ptr() + n0 * Lc * D * 4
         a.M, a.N, a.L, a.D, a.n0, a.n_own, a.ld_s = M, N, Lc, D, n0, n_own, N * Lc
         L.check(L.lib().hero_score_max_bwd(C.byref(a), L.stream()))
-        return dqn, dcn, None, None, None, None, None, None, None
+        return dqn, dcn, None, None, None, None, None, None, None, None, None
 
 
 _STED_WS = {}
@@ -163,7 +168,8 @@ class StEdLossFn(torch.autograd.Function):
     and both cross-entropies (model/pretrain.py:96-110, 128-166) -> scalar."""
 
     @staticmethod
-    def forward(ctx, q2, ctxf, mask, w_st, w_ed, targets):
+    def forward(ctx, q2, ctxf, mask, w_st, w_ed, targets, weight=1.0):
+        """weight: lw_st_ed, folded into the final sum and the backward's upstream gradient."""
         B, Lc, D = ctxf.shape
         q2, ctxf, mask = _f32c(q2), ctxf.contiguous(), _f32c(mask)
         dev = q2.device
@@ -176,8 +182,11 @@ class StEdLossFn(torch.autograd.Function):
         L.check(L.lib().hero_st_ed_fwd(C.byref(a), L.stream()))
         ctx.save_for_backward(q2, ctxf, mask, tg, saved)
         ctx.ws = (w_st, w_ed)
+        ctx.weight = float(weight)
         HF._use(w_st, w_ed)
-        return rows.sum()
+        out = torch.empty((1,), dtype=torch.float32, device=dev)
+        L.check(L.lib().hero_sums_scaled(L.ptr(rows), 1, B, (C.c_float * 1)(float(weight)), L.ptr(out), L.stream()))
+        return out[0]
 
     @staticmethod
     def _args(q2, ctxf, mask, w_st, w_ed, tg, saved, K):
@@ -206,11 +215,12 @@ class StEdLossFn(torch.autograd.Function):
             dwe = torch.zeros(K, dtype=torch.float32, device=dev)
         a = StEdLossFn._args(q2, ctxf, mask, w_st, w_ed, tg, saved, K)
         a.g = L.ptr(_f32c(g).reshape(1))
+        a.g_scale = ctx.weight
         a.dq2, a.dctx, a.dw_st, a.dw_ed = L.ptr(dq2), L.ptr(dctx), L.ptr(dws), L.ptr(dwe)
         a.ws = L.ptr(_sted_workspace(q2.shape[0], dev))
         L.check(L.lib().hero_st_ed_bwd(C.byref(a), L.stream()))
         if sink:
             HF.SINK.done(w_st)
             HF.SINK.done(w_ed)
-            return dq2, dctx, None, None, None, None
-        return dq2, dctx, None, dws.view_as(w_st), dwe.view_as(w_ed), None
+            return dq2, dctx, None, None, None, None, None
+        return dq2, dctx, None, dws.view_as(w_st), dwe.view_as(w_ed), None, None

@@ -153,7 +153,9 @@ class CrossModalTrm(RobertaPreTrainedModel):
             assert gather_index is not None
             T, Lout = gather_index.shape
             flat = self._flat_gather_index(gather_index, img_emb.shape[1], txt_emb.shape[1])
-            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat, tail_rows)
+            # first_grad: get_gather_index (data/data.py:504-512) references a source row twice only from the padded
+            # "identity tail" BEHIND its valid position, and nothing downstream gives a padded position a gradient
+            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat, tail_rows, True)
             return out.view(T, Lout, -1)
         if txt_emb is not None:
             return txt_emb

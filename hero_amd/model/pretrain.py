@@ -114,13 +114,12 @@ class HeroForPretraining(HeroModel):
 
     def _fused_losses(self, batch, frame_embeddings, modularized_query):
         from ..head import RowNormFn, StEdLossFn, VideoRankLossFn
-        z = frame_embeddings.new_zeros((), dtype=torch.float32)
-        loss_st_ed, loss_neg_ctx, loss_neg_q = z, z, z
+        loss_st_ed = loss_neg_ctx = loss_neg_q = None        # a zero tensor only for a term that is really absent (no fill otherwise)
         cmask = batch["c_attn_masks"]
         if self.lw_st_ed != 0 and random.random() > self.drop_svmr_prob:       # model/pretrain.py:74-75
             q2 = HF.linear(modularized_query, self.video_query_linear.weight, self.video_query_linear.bias)
             loss_st_ed = StEdLossFn.apply(q2, frame_embeddings, cmask, self.video_st_predictor.weight,
-                                          self.video_ed_predictor.weight, batch["targets"])
+                                          self.video_ed_predictor.weight, batch["targets"], float(self.lw_st_ed))
         if self.lw_neg_ctx != 0 or self.lw_neg_q != 0:
             qn = RowNormFn.apply(modularized_query, 1e-5)
             cn = RowNormFn.apply(frame_embeddings, 1e-5)
@@ -129,8 +128,15 @@ class HeroForPretraining(HeroModel):
                 qn, cn, cmask, own = dist_utils.gather_negatives(qn, cn, cmask, return_own=True)
             loss_neg_ctx, loss_neg_q = VideoRankLossFn.apply(
                 qn, cn, cmask, own, float(self.margin), self.ranking_loss_type == "lse",
-                bool(self.use_hard_negative), int(self.hard_pool_size), float(self.hard_neg_weight))
-        return (self.lw_st_ed * loss_st_ed, self.lw_neg_ctx * loss_neg_ctx, self.lw_neg_q * loss_neg_q)
+                bool(self.use_hard_negative), int(self.hard_pool_size), float(self.hard_neg_weight),
+                float(self.lw_neg_ctx), float(self.lw_neg_q))
+        # the loss weights (model/pretrain.py:283-290) are folded into the head's own final reductions and backward kernels
+        # (round 5: sum / mean / 3 x mul and their backward nodes were ~12 tiny aten launches per micro-step)
+        if loss_st_ed is None or loss_neg_ctx is None:
+            z = frame_embeddings.new_zeros((), dtype=torch.float32)
+            loss_st_ed = z if loss_st_ed is None else loss_st_ed
+            loss_neg_ctx, loss_neg_q = (z, z) if loss_neg_ctx is None else (loss_neg_ctx, loss_neg_q)
+        return (loss_st_ed, loss_neg_ctx, loss_neg_q)
 
     @staticmethod
     def _conv5(conv, x):

@@ -118,7 +118,8 @@ class TrainStep:
             # 'tvr' / 'vsm': (loss_st_ed, loss_neg_ctx, loss_neg_q) summed (train_vcmr.py:216-226, pretrain.py:283-290);
             # 'mlm' / 'mfm-nce' / 'fom': one loss tensor
             loss = (out[0] + out[1] + out[2]) if isinstance(out, (tuple, list)) else out
-            loss = loss.mean()
+            if loss.dim() > 0:                       # train_vcmr.py:226 `.mean()` of per-GPU losses; a 0-dim loss is its own mean
+                loss = loss.mean()
             loss.backward()
         return loss.detach()
 

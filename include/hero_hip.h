@@ -285,6 +285,12 @@ int hero_gather_rows(const void* a, const void* b, const int32_t* idx, void* out
                      int dtype, hero_stream_t stream);
 /* out[r] = sum_{e in [offsets[r], offsets[r+1])} src[entries[e]].                               */
 /* Replaces HierarchicalVlModel.collect_frame_outputs (model/model.py:156-187).                 */
+/* inv[r] (r < na: rows of a) / inv[na + r] (rows of b) = the FIRST output row of a hero_gather_rows index that reads that
+ * source row, -1 if none (na + nb <= 38400: one workgroup, LDS-resident, deterministic).  With it the backward of a gather
+ * whose repeated references are known to carry no gradient (HERO's f_gather_index: a source row is re-referenced only from
+ * padded positions behind its valid one, data/data.py:504-512, whose gradients are exactly zero) is ONE gather - no zero
+ * fills, no scatter. */
+int hero_inverse_first(const int32_t* idx, int n, int32_t* inv, int na, int nb, hero_stream_t stream);
 int hero_csr_gather_sum(const void* src, const int32_t* offsets, const int32_t* entries, void* out,
                         int rows, int cols, int dtype, hero_stream_t stream);
 /* dst[idx[r]] += src[r] (rows with idx[r] < 0 or == skip_idx are dropped).                      */
@@ -465,7 +471,12 @@ typedef struct HeroScoreMax {
   float* dqn;             /* bwd out [M, D]                                                     */
   float* dcn;             /* bwd out [n_own*L, D]                                               */
   int M, N, L, D, n0, n_own, ld_s;
+  float gc_scale, gq_scale; /* bwd: *gc and *gq are multiplied by these (the loss weights, folded in); 0 means 1 */
 } HeroScoreMax;
+/* out[s] = scales[s] * sum(src[s * seg_len .. (s + 1) * seg_len)), 1..4 segments, fixed summation order: the final
+ * reductions of the loss head (sum of the start / end rows, means of the ranking-loss rows) with the loss weights
+ * (model/pretrain.py:283-290) folded in - one launch instead of sum / mean / mul per loss.  `scales` is a HOST array. */
+int hero_sums_scaled(const float* src, int n_segs, int seg_len, const float* scales, float* out, hero_stream_t stream);
 int hero_score_max_fwd(const HeroScoreMax* a, hero_stream_t stream);
 int hero_score_max_bwd(const HeroScoreMax* a, hero_stream_t stream);
 
@@ -512,7 +523,7 @@ typedef struct HeroStEd {
   float* dw_st;           /* bwd out [K], ACCUMULATED (+=)                                      */
   float* dw_ed;           /* bwd out [K], ACCUMULATED (+=)                                      */
   int B, L, D, K, dtype;
-  int pad_;
+  float g_scale;          /* bwd: *g is multiplied by this (the loss weight, folded in); 0 means 1     */
   float* ws;              /* bwd scratch, hero_st_ed_bwd_workspace_bytes(B) bytes, ZERO before the first */
                           /* use (the kernel leaves its arrival counter at zero): per-pair shares of     */
                           /* dw_st / dw_ed, folded in pair order by the last workgroup to arrive - the   */

@@ -1,6 +1,7 @@
 """Kernel-level parity: every C-ABI op against a plain fp32 torch restatement of the same op on
 the same seeded inputs.  Needs a real MI355X (-m gpu)."""
 import math
+import os
 
 import pytest
 import torch
@@ -847,6 +848,59 @@ def test_row_stack_and_split_in_place(HF, Lb):
     want[:100] = wo.float().repeat_interleave(2, 0)
     want[200:] = wq.float()
     torch.testing.assert_close(x.grad.float(), want, rtol=1e-2, atol=1e-2)
+
+
+def test_gather_backward_through_the_first_occurrence_map(HF, Lb):
+    """Round 5: hero_inverse_first + GatherRowsFn(first_grad=True).  The reference's gather index (data/data.py:504-512) names a
+    source row a second time only from a padded position BEHIND its valid one, and padded positions receive exactly zero
+    gradient - then the backward is one gather through the first-occurrence map.  Checked: the map itself, the gradients
+    against the scatter-add backward when the repeated references carry zero gradient, and that a reference's reference-built
+    index (tests/golden/case_collate.npz) has its repeats at padded positions only."""
+    import numpy as np
+    dtype = torch.bfloat16
+    na, nb, n = 40, 100, 160
+    g = torch.Generator().manual_seed(11)
+    first = torch.randperm(na + nb, generator=g)[:120]                       # 120 distinct sources, valid part
+    again = first[torch.randint(0, 120, (n - 120,), generator=g)]            # repeats, all behind the valid part
+    src = torch.cat([first, again])
+    idx = torch.where(src < na, src, -(src - na) - 2).to(torch.int32)
+    idx[7] = -1                                                              # a position that reads nothing
+    idx_d = idx.cuda()
+    inv = torch.empty(na + nb, dtype=torch.int32, device="cuda")
+    Lb.check(Lb.lib().hero_inverse_first(Lb.ptr(idx_d), n, Lb.ptr(inv), na, nb, Lb.stream()))
+    want = torch.full((na + nb,), -1, dtype=torch.int32)
+    for j in range(n - 1, -1, -1):
+        v = int(idx[j])
+        if v >= 0:
+            want[v] = j
+        elif v <= -2:
+            want[na - v - 2] = j
+    assert torch.equal(inv.cpu(), want)
+    assert Lb.lib().hero_inverse_first(Lb.ptr(idx_d), n, Lb.ptr(inv), 30000, 30000, Lb.stream()) != 0      # beyond the LDS table: refused
+    a0, b0 = rnd(na, 64, dtype=dtype, seed=1), rnd(nb, 64, dtype=dtype, seed=2)
+    w = rnd(n, 64, dtype=dtype, seed=3)
+    w[120:] = 0                                                              # the repeats (padded positions) carry no gradient
+    grads = []
+    for fg in (False, True):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = HF.GatherRowsFn.apply(a, b, idx_d, 0, fg)
+        (out.float() * w.float()).sum().backward()
+        grads.append((a.grad.clone(), b.grad.clone(), out.detach()))
+    assert torch.equal(grads[0][2], grads[1][2])
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # the reference's own index tensors: every repeated reference sits at a masked position
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "case_collate.npz"), allow_pickle=True)
+    keys = [k for k in z.files if k.endswith("f_gather_index")]
+    assert keys
+    for k in keys:
+        gi, m = z[k], z[k.replace("f_gather_index", "f_attn_masks")]
+        for row_g, row_m in zip(gi, m):
+            first_pos = {}
+            for j, v in enumerate(row_g.tolist()):
+                first_pos.setdefault(v, j)
+            for j, (v, ok) in enumerate(zip(row_g.tolist(), row_m.tolist())):
+                if ok:
+                    assert first_pos[v] == j, (k, j, v)      # a VALID position is always the first reference to its source row
 
 
 def test_attention_dropout_adjoint(HF, Lb):

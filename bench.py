@@ -721,7 +721,7 @@ def main():
                 sec[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             _forget_previous_models()
         try:
-            sec["feed"] = feed_run(device, rank, steps=12, warmup=4)
+            sec["feed"] = feed_run(device, rank, steps=20, warmup=6)       # as many timed steps as the headline run it is compared with
         except Exception as e:                           # noqa: BLE001
             sec["feed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         sec["wall_s"] = round(time.perf_counter() - t_sec, 1)

@@ -195,8 +195,14 @@ class DeviceCollate:
         self.inverse = z(T * self.Lf)
         self._counts = z(B * NF)
         self._row_vid = z(T)
-        self._in = {"sub_nfrm": z(T), "sub_ntok": z(T), "sub_frm_off": z(T + 1), "sub_frm": z(max(cap, 1)),
-                    "vid_sub_off": z(B + 1), "vid_nfrm": z(B)}
+        # the six length arrays live in ONE int32 buffer (slots padded to 4 elements): a feeder refreshes them with one copy
+        sizes = {"sub_nfrm": T, "sub_ntok": T, "sub_frm_off": T + 1, "sub_frm": max(cap, 1), "vid_sub_off": B + 1, "vid_nfrm": B}
+        self._in_off, off = {}, 0
+        for k, n in sizes.items():
+            self._in_off[k] = (off, n)
+            off += (n + 3) & ~3
+        self._in_flat = z(off)
+        self._in = {k: self._in_flat[o:o + n] for k, (o, n) in self._in_off.items()}
 
     @classmethod
     def for_batch(cls, batch, device, **kw):
@@ -214,6 +220,11 @@ class DeviceCollate:
         """Copy the length arrays into the device-side input slots (a few hundred bytes, stream-ordered).
         lengths: host arrays (video_collate's batch["lengths"]) or, with src_device=True, a dict of int32 DEVICE
         tensors of exactly the slot sizes (a staging copy made on another stream: StaticBatchFeeder)."""
+        if src_device and torch.is_tensor(lengths):          # a flat staging copy of the whole input buffer (same layout)
+            if lengths.shape != self._in_flat.shape:
+                raise ValueError("DeviceCollate: flat length buffer of %d entries, expected %d" % (lengths.numel(), self._in_flat.numel()))
+            self._in_flat.copy_(lengths, non_blocking=True)
+            return self
         for k, dst in self._in.items():
             src = lengths[k] if src_device else torch.as_tensor(lengths[k], dtype=torch.int32)
             if src.numel() > dst.numel() or (k in ("sub_nfrm", "sub_ntok", "vid_nfrm") and src.numel() != dst.numel()):

@@ -172,7 +172,8 @@ class StaticBatchFeeder:
         # wait_event on an event of the compute stream cost 0.28 ms per step (tools/lab/feedprobe.py): the runtime turns
         # the recorded event into a barrier packet with a completion signal in front of the step's graph launch.
         self.stage = [{k: dev(host_batch[k]) for k in self.shapes} for _ in range(2)]
-        self.stage_len = [{k: torch.zeros_like(v) for k, v in self.dc._in.items()} for _ in range(2)]
+        self.stage_len = [torch.zeros_like(self.dc._in_flat) for _ in range(2)]           # the six length arrays, one buffer
+        self._pin_len = [torch.zeros(self.dc._in_flat.shape, dtype=torch.int32).pin_memory() for _ in range(2)]
         self.copy_stream = torch.cuda.Stream(self.device)
         self._landed = [torch.cuda.Event(), torch.cuda.Event()]
         self._consumed = [torch.cuda.Event(), torch.cuda.Event()]
@@ -211,13 +212,14 @@ class StaticBatchFeeder:
         with torch.cuda.stream(self.copy_stream):
             for k in self.shapes:
                 self.stage[s][k].copy_(host_batch[k], non_blocking=True)
-            for k, dst in self.stage_len[s].items():
-                src = torch.as_tensor(host_batch["lengths"][k], dtype=torch.int32)
-                if src.numel() > dst.numel():
-                    raise ValueError("StaticBatchFeeder: %s has %d entries (capacity %d)" % (k, src.numel(), dst.numel()))
-                if src.numel() < dst.numel():
-                    dst.zero_()
-                dst[:src.numel()].copy_(src, non_blocking=True)
+            flat = self._pin_len[s]                           # one pinned image of the input buffer, one H2D copy
+            flat.zero_()
+            for k, (o, n) in self.dc._in_off.items():
+                src = torch.as_tensor(host_batch["lengths"][k], dtype=torch.int32).reshape(-1)
+                if src.numel() > n or (k in ("sub_nfrm", "sub_ntok", "vid_nfrm") and src.numel() != n):
+                    raise ValueError("StaticBatchFeeder: %s has %d entries (capacity %d)" % (k, src.numel(), n))
+                flat[o:o + src.numel()] = src
+            self.stage_len[s].copy_(flat, non_blocking=True)
             # Segment orders of the id tensors (embedding-gradient scatter): a stable argsort of <= 10 k ids is ~0.3 ms of numpy
             # on a host that has ~6 ms of slack per step; on the device it was a one-workgroup radix sort inside every commit
             # (69 + 20 us of the commit graph's 239: tools/lab/feedprobe.py).

@@ -525,7 +525,9 @@ def main():
 
     dt, loss_val = timed_run()
     graph_mode = trainer.use_graph
-    try_graph = dist_on and not args.no_graph and os.environ.get("HERO_DP_GRAPH", "1") not in ("", "0")
+    # (the captured run needs device-side collectives: over gloo - the plumbing run - they are host-staged and cannot be captured)
+    try_graph = (dist_on and not args.no_graph and os.environ.get("HERO_DP_GRAPH", "1") not in ("", "0")
+                 and torch.distributed.get_backend() == "nccl")
     eager_ms = dt / args.steps * 1e3
 
     # ---- N > 1: what the collectives cost, so that the line itself shows that RCCL saw N ranks ---------------------

@@ -100,7 +100,8 @@ class AdamW(C.Structure):
 
 class TensorDesc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("n", C.c_uint64), ("group", C.c_int32), ("step_lag", C.c_int32)]
+                ("n", C.c_uint64), ("group", C.c_int32), ("step_lag", C.c_int32),
+                ("shadow", C.c_void_p), ("shadow_dtype", C.c_int32), ("pad_", C.c_int32)]
 
 
 class AdamWGroup(C.Structure):

@@ -108,7 +108,8 @@ def notify_weights_updated():
 def clear_weight_cache():
     _WGEN[0] += 1
     _WCACHE.clear()
-    _REFRESH["sig"] = _REFRESH["tables"] = None
+    for k in [k for k in _REFRESH if k not in _REFRESH_PINNED]:
+        del _REFRESH[k]
 
 
 _TRUST = [False]
@@ -127,19 +128,54 @@ class weights_frozen:
         _TRUST[0] = self.prev
 
 
-_REFRESH = {"sig": None, "tables": None}
+_REFRESH = {}              # descriptor-table signature -> device tables of hero_copy_multi (several: the tasks of a multi-task run
+_REFRESH_PINNED = set()    # update different parameter sets); tables used under stream capture are never dropped (a graph holds their addresses)
+_SHADOW = {"gen": -1, "map": {}}
 
 
-def refresh_weight_cache():
+def straight_copy_of(p):
+    """(device pointer, dtype code) of the cached compute copy region that holds parameter `p` in its own flat element order
+    (the straight bf16 / fp32 copies of `packed`; a parameter inside a row-concatenated copy - Q, K, V - owns a contiguous
+    region of it), or None.  The fused AdamW writes these regions from its registers (HeroTensorDesc.shadow), so the
+    optimiser pass produces the next step's straight copies and refresh_weight_cache only has the transposes left."""
+    if _SHADOW["gen"] != (_WGEN[0], len(_WCACHE)):
+        m = {}
+        for key, (_, out, params) in _WCACHE.items():
+            if len(key) != 2:
+                continue                                # transposed copies are not flat images of their parameters
+            off = 0
+            for q in params:
+                m[id(q)] = (out.data_ptr() + off * out.element_size(), L.dt(out), q.numel())
+                off += q.numel()
+        _SHADOW["gen"], _SHADOW["map"] = (_WGEN[0], len(_WCACHE)), m
+    hit = _SHADOW["map"].get(id(p))
+    return (hit[0], hit[1]) if hit is not None and hit[2] == p.numel() else None
+
+
+def refresh_weight_cache(shadowed=None):
     """Re-derive every cached compute copy from the current fp32 master weights NOW, in ONE launch
     (hero_copy_multi over a device-resident descriptor table: ~160 cast / transpose launches per
     optimiser step otherwise).  Called right after the optimiser step - eagerly, and inside the
-    captured hipGraph - so the next forward finds the cache valid."""
+    captured hipGraph - so the next forward finds the cache valid.
+    shadowed: ids of the parameters whose straight copies the optimiser pass has just written itself (round 5:
+    hero_amd.optim.AdamW.last_shadowed); a straight copy all of whose parameters are in it is not copied again."""
     if not _WCACHE:
         return
     entries = list(_WCACHE.items())
+    if shadowed:
+        live = [(k, v) for k, v in entries if len(k) != 2 or not all(id(q) in shadowed for q in v[2])]
+        skipped = [(k, v) for k, v in entries if len(k) == 2 and all(id(q) in shadowed for q in v[2])]
+        ep = _WEPOCH[0]
+        for key, (_, out, params) in skipped:          # already current: written by the optimiser kernel
+            _WCACHE[key] = ((tuple(q._version for q in params), tuple(q.data_ptr() for q in params), ep), out, params)
+        entries = live
+        if not entries:
+            return
     tsig = tuple((key, val[1].data_ptr(), tuple(p.data_ptr() for p in val[2])) for key, val in entries)
-    if _REFRESH["sig"] != tsig:
+    if tsig not in _REFRESH:
+        if len(_REFRESH) > 16:
+            for k in [k for k in _REFRESH if k not in _REFRESH_PINNED][:8]:
+                del _REFRESH[k]
         descs, tdesc, tidx = [], [], []
         for key, (_, out, params) in entries:
             transposed = len(key) == 3
@@ -163,10 +199,11 @@ def refresh_weight_cache():
         dev = entries[0][1][1].device
         arr = (L.CopyDesc * len(descs))(*descs)
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        _REFRESH["tables"] = (raw, torch.tensor(tdesc, dtype=torch.int32, device=dev),
-                              torch.tensor(tidx, dtype=torch.int32, device=dev), len(tdesc))
-        _REFRESH["sig"] = tsig
-    raw, tdesc, tidx, n = _REFRESH["tables"]
+        _REFRESH[tsig] = (raw, torch.tensor(tdesc, dtype=torch.int32, device=dev),
+                          torch.tensor(tidx, dtype=torch.int32, device=dev), len(tdesc))
+    if torch.cuda.is_current_stream_capturing():
+        _REFRESH_PINNED.add(tsig)
+    raw, tdesc, tidx, n = _REFRESH[tsig]
     L.check(L.lib().hero_copy_multi(raw.data_ptr(), tdesc.data_ptr(), tidx.data_ptr(), n, L.stream()))
     ep = _WEPOCH[0]
     for key, (_, out, params) in entries:
@@ -196,7 +233,7 @@ def packed(params, dtype):
         L.check(L.lib().hero_cast(L.ptr(p.detach().contiguous()), dst.data_ptr(), n, L.F32,
                                   L.dt(out), L.stream()))
         off += p.shape[0]
-    if hit is None:
+    if hit is None or not reuse:
         _WGEN[0] += 1
     _WCACHE[key] = (sig, out, params)
     return out
@@ -223,7 +260,7 @@ def packed_t(params, dtype):
                                             out.data_ptr() + off * out.element_size(), p.shape[0], kin,
                                             cols, L.dt(out), L.stream()))
         off += p.shape[0]
-    if hit is None:
+    if hit is None or not reuse:
         _WGEN[0] += 1
     _WCACHE[key] = (sig, out, params)
     return out
@@ -867,6 +904,8 @@ def reset_caches():
     several models in a row (bench.py's secondary workloads: each would otherwise pay for its predecessors' copies).
     Not while a captured hipGraph that references those buffers is still going to be replayed."""
     clear_weight_cache()
+    _REFRESH.clear()
+    _REFRESH_PINNED.clear()
     _MEMO.clear()
     _WS.clear()
     _WPLANS.clear()

@@ -30,6 +30,11 @@ class AdamW(Optimizer):
         self._pinned = []         # tables built or used while a hipGraph was capturing: the graph holds their addresses
         self._tsteps = None       # device-state mode: per-parameter step counts on the device (int32 [n params])
         self._slots = None        # parameter -> slot in _tsteps
+        # round 5: the kernel also writes the cached straight compute copy (bf16) of every parameter that has one
+        # (functional.straight_copy_of), so the weight-copy refresh after the step only has the transposes left;
+        # last_shadowed = ids of the parameters whose copies the last step() wrote
+        self.write_copies = True
+        self.last_shadowed = frozenset()
 
     def load_state_dict(self, state_dict):
         """A restore replaces the moment tensors the descriptor tables point at: drop the tables (the ones captured
@@ -90,8 +95,10 @@ class AdamW(Optimizer):
             g = p.grad
             if not (p.is_contiguous() and g.is_contiguous()):
                 raise RuntimeError("hero_amd AdamW needs contiguous parameters and gradients")
+            sh = HF.straight_copy_of(p) if self.write_copies else None
             descs[i] = L.TensorDesc(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                    p.numel(), gi, self._slots[p] if slots else self._global_step - st["step"])
+                                    p.numel(), gi, self._slots[p] if slots else self._global_step - st["step"],
+                                    sh[0] if sh else None, sh[1] if sh else 0, 0)
             n = -(-p.numel() // chunk)
             ct.extend([i] * n)
             ci.extend(range(n))
@@ -138,6 +145,9 @@ class AdamW(Optimizer):
         else:
             sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
                          self.state[p]["exp_avg_sq"].data_ptr(), self._global_step - self.state[p]["step"]) for _, p in active)
+        shadows = tuple(HF.straight_copy_of(p) for _, p in active) if self.write_copies else ()
+        sig = sig + (shadows,)                       # a table holds the copies' addresses: new copies, new table
+        self.last_shadowed = frozenset(id(p) for (_, p), sh in zip(active, shadows) if sh is not None)
         capturing = torch.cuda.is_current_stream_capturing()
         if sig not in self._tables:
             if len(self._tables) >= 16 and not capturing:

@@ -133,7 +133,8 @@ class TrainStep:
                             grad_scale=1.0 / D.world_size(), skip=set(untouched),
                             step_tensor=self._step_t if device_state else None,
                             lr_tensor=self._lr_t if device_state else None)
-        HF.refresh_weight_cache()                    # all bf16 / transposed weight copies, one launch
+        # the transposed weight copies in one launch; the straight ones were written by the AdamW kernel itself
+        HF.refresh_weight_cache(shadowed=self.optimizer.last_shadowed)
         self.arena.zero()
 
     def _set_lr(self):

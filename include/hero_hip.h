@@ -366,6 +366,9 @@ typedef struct HeroTensorDesc {
   uint64_t n;
   int32_t group;
   int32_t step_lag;
+  void* shadow;          /* optional: a compute copy of p with the SAME flat element order (bf16 or fp32, shadow_dtype) that */
+  int32_t shadow_dtype;  /* the kernel rewrites from the updated values - the optimiser pass produces the next step's weight  */
+  int32_t pad_;          /* copies instead of a separate read of every master weight (hero_copy_multi)                        */
 } HeroTensorDesc;
 typedef struct HeroAdamWGroup {
   float lr, beta1, beta2, eps, weight_decay;

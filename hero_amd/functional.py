@@ -152,23 +152,24 @@ def straight_copy_of(p):
     return (hit[0], hit[1]) if hit is not None and hit[2] == p.numel() else None
 
 
-def refresh_weight_cache(shadowed=None):
+def refresh_weight_cache(straight_done=False):
     """Re-derive every cached compute copy from the current fp32 master weights NOW, in ONE launch
     (hero_copy_multi over a device-resident descriptor table: ~160 cast / transpose launches per
     optimiser step otherwise).  Called right after the optimiser step - eagerly, and inside the
     captured hipGraph - so the next forward finds the cache valid.
-    shadowed: ids of the parameters whose straight copies the optimiser pass has just written itself (round 5:
-    hero_amd.optim.AdamW.last_shadowed); a straight copy all of whose parameters are in it is not copied again."""
+    straight_done: the optimiser pass has written the straight copies of every parameter it updated itself (round 5:
+    hero_amd.optim.AdamW with write_copies - a parameter it did not update has not changed), so only the TRANSPOSED copies
+    are re-derived.  The set of transposed copies does not depend on which task's parameters the step updated: one
+    descriptor table per generation of the cache, built by the eager warm-up steps, found again under capture."""
     if not _WCACHE:
         return
     entries = list(_WCACHE.items())
-    if shadowed:
-        live = [(k, v) for k, v in entries if len(k) != 2 or not all(id(q) in shadowed for q in v[2])]
-        skipped = [(k, v) for k, v in entries if len(k) == 2 and all(id(q) in shadowed for q in v[2])]
+    if straight_done:
         ep = _WEPOCH[0]
-        for key, (_, out, params) in skipped:          # already current: written by the optimiser kernel
-            _WCACHE[key] = ((tuple(q._version for q in params), tuple(q.data_ptr() for q in params), ep), out, params)
-        entries = live
+        for key, (_, out, params) in entries:
+            if len(key) == 2:                           # already current: written by the optimiser kernel, or unchanged
+                _WCACHE[key] = ((tuple(q._version for q in params), tuple(q.data_ptr() for q in params), ep), out, params)
+        entries = [(k, v) for k, v in entries if len(k) != 2]
         if not entries:
             return
     tsig = tuple((key, val[1].data_ptr(), tuple(p.data_ptr() for p in val[2])) for key, val in entries)

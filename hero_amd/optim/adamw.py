@@ -35,6 +35,7 @@ class AdamW(Optimizer):
         # last_shadowed = ids of the parameters whose copies the last step() wrote
         self.write_copies = True
         self.last_shadowed = frozenset()
+        self.last_active = []     # (group index, parameter) of the last step(): what TrainStep hands to prebuild()
 
     def load_state_dict(self, state_dict):
         """A restore replaces the moment tensors the descriptor tables point at: drop the tables (the ones captured
@@ -136,6 +137,21 @@ class AdamW(Optimizer):
         if not active:
             return loss
         tsteps = self._device_steps(active[0][1].device) if device_state else None
+        self.last_active = active
+        sig = self._table_for(active, device_state)
+        raw, t_ct, t_ci, n_chunks = self._tables[sig]
+        return self._launch(raw, t_ct, t_ci, n_chunks, len(active), tsteps, grad_sumsq, max_grad_norm, grad_scale, step_tensor, lr_tensor, loss)
+
+    def prebuild(self, active, device_state=True):
+        """Build (outside any stream capture) the descriptor table a later captured step() over the same parameters will
+        need: a table holds the addresses of the parameters' straight compute copies, and a copy created since the last
+        capture (another task's first forward) means a new table - whose upload is not capturable.  TrainStep calls this
+        before it re-captures a task."""
+        if active:
+            self._device_steps(active[0][1].device)
+            self._table_for(list(active), device_state)
+
+    def _table_for(self, active, device_state):
         if device_state:
             # per-parameter counts live on the device and are advanced by the kernel for the ACTIVE parameters only:
             # graphs of other tasks never touch the counters of parameters they skip (the reference's state['step'],
@@ -155,7 +171,9 @@ class AdamW(Optimizer):
             self._tables[sig] = self._build_table(active, slots=device_state)
         if capturing and not any(t is self._tables[sig] for t in self._pinned):
             self._pinned.append(self._tables[sig])
-        raw, t_ct, t_ci, n_chunks = self._tables[sig]
+        return sig
+
+    def _launch(self, raw, t_ct, t_ci, n_chunks, n_active, tsteps, grad_sumsq, max_grad_norm, grad_scale, step_tensor, lr_tensor, loss):
         a = L.AdamWMulti()
         a.descs, a.chunk_tensor, a.chunk_index, a.n_chunks = raw.data_ptr(), t_ct.data_ptr(), t_ci.data_ptr(), n_chunks
         for gi, group in enumerate(self.param_groups):
@@ -163,7 +181,7 @@ class AdamW(Optimizer):
             a.groups[gi] = L.AdamWGroup(group["lr"], b1, b2, group["eps"], group["weight_decay"])
         a.step = max(self._global_step, 1)
         a.step_ptr, a.lr_ptr = L.ptr(step_tensor), L.ptr(lr_tensor)
-        a.tensor_steps, a.n_tensors = L.ptr(tsteps), len(active)
+        a.tensor_steps, a.n_tensors = L.ptr(tsteps), n_active
         a.grad_sumsq = L.ptr(grad_sumsq)
         a.max_grad_norm, a.grad_scale = max_grad_norm, grad_scale
         L.check(L.lib().hero_adamw_multi(C.byref(a), L.stream()))

@@ -134,7 +134,7 @@ class TrainStep:
                             step_tensor=self._step_t if device_state else None,
                             lr_tensor=self._lr_t if device_state else None)
         # the transposed weight copies in one launch; the straight ones were written by the AdamW kernel itself
-        HF.refresh_weight_cache(shadowed=self.optimizer.last_shadowed)
+        HF.refresh_weight_cache(straight_done=bool(getattr(self.optimizer, "write_copies", False)))
         self.arena.zero()
 
     def _set_lr(self):
@@ -206,6 +206,8 @@ class TrainStep:
         self._graphs[task] = (ga, loss_a, gb, loss_b, batch)
         self._graph_gen = getattr(self, "_graph_gen", {})
         self._graph_gen[task] = HF.weight_cache_generation()
+        self._active_of = getattr(self, "_active_of", {})
+        self._active_of[task] = list(getattr(self.optimizer, "last_active", []))     # for prebuild() before a re-capture
 
     def prepare(self, batch, task=None):
         """One-time setup outside any timed region: in graph mode the eager warm-up micro-steps and the
@@ -230,6 +232,8 @@ class TrainStep:
         accum = self.opts.gradient_accumulation_steps
         if self.micro % accum == 0 and self._graph_gen[task] != HF.weight_cache_generation():
             torch.cuda.synchronize()                 # window start: re-capture against the current set of weight copies
+            if hasattr(self.optimizer, "prebuild"):  # its descriptor table holds the copies' addresses: build the new one eagerly
+                self.optimizer.prebuild(self._active_of.get(task, []))
             self._record(self._graphs[task][4], task)
         ga, loss_a, gb, loss_b, static_batch = self._graphs[task]
         if batch is not static_batch:

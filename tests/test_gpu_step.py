@@ -116,7 +116,7 @@ def test_one_launch_weight_refresh_equals_per_tensor_casts():
 def test_adamw_writes_the_straight_compute_copies():
     """Round 5: the fused AdamW kernel writes the cached straight (bf16, row-concatenated) compute copy of every parameter it
     updates (HeroTensorDesc.shadow) - the same rounding of the same fp32 values as hero_copy_multi - and
-    refresh_weight_cache(shadowed=...) then only has the transposed copies left; a parameter the step skips keeps its copy;
+    refresh_weight_cache(straight_done=True) then only has the transposed copies left; a parameter the step skips keeps its copy;
     fp32 packed copies (bias vectors) are shadows too."""
     import hero_amd
     from hero_amd import functional as HF, optim
@@ -143,13 +143,13 @@ def test_adamw_writes_the_straight_compute_copies():
             assert torch.equal(W, ref.to(torch.bfloat16)) and torch.equal(Lc, lone.detach().to(torch.bfloat16))
             assert torch.equal(B, torch.cat([p.detach() for p in bs])) and torch.equal(Ic, idle_before)
             assert torch.equal(Wt, Wt_before) and not torch.equal(Wt, ref.t().contiguous().to(torch.bfloat16))
-            HF.refresh_weight_cache(shadowed=opt.last_shadowed)
+            HF.refresh_weight_cache(straight_done=True)
             assert torch.equal(Wt, ref.t().contiguous().to(torch.bfloat16))
             assert HF.packed(ws, torch.bfloat16) is W and HF.packed_t(ws, torch.bfloat16) is Wt      # cache hits
         opt.write_copies = False                        # the old path: nothing shadowed, the refresh copies everything
         opt.step()
         assert opt.last_shadowed == frozenset() and not torch.equal(W, torch.cat([p.detach() for p in ws], 0).to(torch.bfloat16))
-        HF.refresh_weight_cache(shadowed=opt.last_shadowed)
+        HF.refresh_weight_cache(straight_done=opt.write_copies)
         assert torch.equal(W, torch.cat([p.detach() for p in ws], 0).to(torch.bfloat16))
     finally:
         HF.clear_weight_cache()

@@ -30,10 +30,13 @@ class AdamW(Optimizer):
         self._pinned = []         # tables built or used while a hipGraph was capturing: the graph holds their addresses
         self._tsteps = None       # device-state mode: per-parameter step counts on the device (int32 [n params])
         self._slots = None        # parameter -> slot in _tsteps
-        # round 5: the kernel also writes the cached straight compute copy (bf16) of every parameter that has one
-        # (functional.straight_copy_of), so the weight-copy refresh after the step only has the transposes left;
-        # last_shadowed = ids of the parameters whose copies the last step() wrote
-        self.write_copies = True
+        # round 5: the kernel can also write the cached straight compute copy (bf16) of every parameter that has one
+        # (functional.straight_copy_of), so that the weight-copy refresh after the step only has the transposes left.
+        # Built because three verdicts priced it at -0.03 ms per micro-step; MEASURED (rocprofv3, steady state, per optimiser
+        # step): adamw_multi_kernel 536 -> 584 us (8-byte bf16 stores between the 16-byte fp32 ones), copy_multi_kernel
+        # 137 -> 106 us (the transposes are the expensive half) = +17 us, step time unchanged within noise in a same-box
+        # A/B.  OFF by default; last_shadowed = ids of the parameters whose copies the last step() wrote.
+        self.write_copies = False
         self.last_shadowed = frozenset()
         self.last_active = []     # (group index, parameter) of the last step(): what TrainStep hands to prebuild()
 

@@ -114,7 +114,7 @@ def test_one_launch_weight_refresh_equals_per_tensor_casts():
 
 
 def test_adamw_writes_the_straight_compute_copies():
-    """Round 5: the fused AdamW kernel writes the cached straight (bf16, row-concatenated) compute copy of every parameter it
+    """Round 5 (opt-in, `AdamW.write_copies`): the fused AdamW kernel writes the cached straight (bf16, row-concatenated) compute copy of every parameter it
     updates (HeroTensorDesc.shadow) - the same rounding of the same fp32 values as hero_copy_multi - and
     refresh_weight_cache(straight_done=True) then only has the transposed copies left; a parameter the step skips keeps its copy;
     fp32 packed copies (bias vectors) are shadows too."""
@@ -132,6 +132,8 @@ def test_adamw_writes_the_straight_compute_copies():
         Lc, Ic = HF.packed((lone,), torch.bfloat16), HF.packed((idle,), torch.bfloat16)
         idle_before = Ic.clone()
         opt = optim.AdamW([{"params": ws + bs + [lone, idle], "weight_decay": 0.01}], lr=1e-2)
+        assert opt.write_copies is False                 # measured neutral-to-negative on MI355X: off by default (optim/adamw.py)
+        opt.write_copies = True
         for p in ws + bs + [lone]:
             p.grad = torch.randn_like(p)
         for _ in range(2):

@@ -117,3 +117,45 @@ def test_oracle_lse_hard_negative_branch_against_reference():
     for n in names:
         want = torch.from_numpy(Z["narrow.lse.grad." + n])
         assert (Pq[n].grad - want).abs().max() <= 1e-5 * want.abs().max() + 1e-7, n
+
+
+def test_reference_gather_index_names_a_source_row_first_from_its_valid_position():
+    """Round 5: the embedding interleave's backward is ONE gather through the first-occurrence map of f_gather_index
+    (hero_inverse_first, functional.GatherRowsFn(first_grad=True)) - exact only because, in every index tensor the REFERENCE's
+    get_gather_index produces (data/data.py:504-512; ten batches of case_collate.npz incl. the narrow ones, a zero-frame subtitle
+    and the 511 clamp), a valid position is always the FIRST reference to its source row: the repeats sit in the padded
+    identity tail, whose gradients are exactly zero."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "case_collate.npz"), allow_pickle=True)
+    keys = [k for k in z.files if k.endswith("f_gather_index")]
+    assert len(keys) >= 10
+    checked = repeats = 0
+    for k in keys:
+        gi, m = z[k], z[k.replace("f_gather_index", "f_attn_masks")]
+        assert gi.shape == m.shape
+        for row_g, row_m in zip(gi.tolist(), m.tolist()):
+            first_pos = {}
+            for j, v in enumerate(row_g):
+                first_pos.setdefault(v, j)
+            repeats += len(row_g) - len(first_pos)
+            for j, (v, ok) in enumerate(zip(row_g, row_m)):
+                if ok:
+                    assert first_pos[v] == j, (k, j, v)
+                    checked += 1
+    assert checked > 2000 and repeats > 0           # the fixtures do contain repeated references (all of them padded)
+
+
+def test_host_segment_order_is_a_stable_sort_with_dropped_rows_last():
+    """hero_amd.functional.host_segment_order (what StaticBatchFeeder.prefetch computes instead of the device's
+    hero_segment_sort): rows by (id, row), ids < 0 or == skip behind every real destination, stable."""
+    import numpy as np
+    import torch
+    from hero_amd import functional as HF
+    g = torch.Generator().manual_seed(3)
+    for n, vocab, skip in ((9600, 50272, 1), (33, 5, 0), (100, 7, -1)):
+        ids = torch.randint(0, vocab, (n,), generator=g)
+        ids[::9] = -1
+        key = torch.where((ids < 0) | (ids == skip), torch.full_like(ids, 1 << 40), ids)
+        want = torch.sort(key, stable=True).indices.to(torch.int32)
+        got = torch.from_numpy(HF.host_segment_order(ids.numpy(), skip))
+        assert torch.equal(got, want)

@@ -11,13 +11,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HERO_HIP_LIB") or os.path.join(_HERE, "libhero_hip.so")   # HERO_HIP_LIB: alternative build (A/B runs)
 
-ABI_VERSION = 2          # include/hero_hip.h HERO_ABI_VERSION this binding's struct layouts were written against
+ABI_VERSION = 3          # include/hero_hip.h HERO_ABI_VERSION this binding's struct layouts were written against
 F32, BF16 = 0, 1
 LAYOUT_K, LAYOUT_O = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_DG, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "hero_last_error", "hero_abi_version", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_probe_mfma", "hero_probe_hbm", "hero_gemm_force_config", "hero_layernorm_fwd",
+    "hero_last_error", "hero_abi_version", "hero_abi_struct_count", "hero_abi_struct_bytes", "hero_gemm", "hero_gemm_splits", "hero_fold_slabs", "hero_wgrad_group", "hero_wgrad_batch_plan", "hero_wgrad_batch", "hero_prof_enable", "hero_prof_read", "hero_probe_mfma", "hero_probe_hbm", "hero_gemm_force_config", "hero_layernorm_fwd",
     "hero_layernorm_bwd_workspace_bytes", "hero_layernorm_bwd", "hero_colsum_workspace_bytes",
     "hero_colsum", "hero_colsum_multi", "hero_colsum_multi_workspace_bytes", "hero_layernorm_bwd_blocks", "hero_attention_fwd", "hero_attention_bwd", "hero_attention_max_len", "hero_attention_max_packed_len", "hero_attention_stats_ok", "hero_attention_force_ppw",
     "hero_gather_rows", "hero_inverse_first", "hero_csr_gather_sum", "hero_scatter_add_rows", "hero_segment_sort_workspace_bytes", "hero_scatter_add_sorted_workspace_bytes", "hero_segment_sort", "hero_scatter_add_sorted", "hero_cast", "hero_transpose_cast", "hero_copy_multi",
@@ -100,8 +100,7 @@ class AdamW(C.Structure):
 
 class TensorDesc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
-                ("n", C.c_uint64), ("group", C.c_int32), ("step_lag", C.c_int32),
-                ("shadow", C.c_void_p), ("shadow_dtype", C.c_int32), ("pad_", C.c_int32)]
+                ("n", C.c_uint64), ("group", C.c_int32), ("step_lag", C.c_int32)]
 
 
 class AdamWGroup(C.Structure):
@@ -161,6 +160,16 @@ class CommBucket(C.Structure):
     _fields_ = [("buf", C.c_void_p), ("count", C.c_size_t), ("dtype", C.c_int), ("pad_", C.c_int)]
 
 
+# HERO_STRUCT_* id (include/hero_hip.h) -> the ctypes mirror of that struct; lib() holds every sizeof against the library's
+ABI_STRUCTS = [Dropout, GemmEpilogue, WgradProblem, LnFwd, LnBwd, Colsum, Attn, AdamW, TensorDesc, AdamWGroup, AdamWMulti,
+               CopyDesc, QueryPool, RowNorm, ScoreMax, RankLoss, StEd, CrossEntropy, Derive, CommBucket]
+
+
+def abi_struct_sizes():
+    """{struct name: ctypes.sizeof} of this binding, in HERO_STRUCT_* order (tests/golden/abi_sizes.json pins it per version)."""
+    return {st.__name__: C.sizeof(st) for st in ABI_STRUCTS}
+
+
 _lib = None
 
 
@@ -179,6 +188,13 @@ def lib():
         if have != ABI_VERSION:
             raise RuntimeError("hero_amd: %s reports ABI version %d, this binding was written against %d (struct layouts "
                                "differ: rebuild with `python -m hero_amd.build --force`)" % (LIB_PATH, have, ABI_VERSION))
+        L.hero_abi_struct_bytes.argtypes = [C.c_int]
+        if L.hero_abi_struct_count() != len(ABI_STRUCTS):
+            raise RuntimeError("hero_amd: %s declares %d ABI structs, this binding mirrors %d" % (LIB_PATH, L.hero_abi_struct_count(), len(ABI_STRUCTS)))
+        bad = [(st.__name__, C.sizeof(st), L.hero_abi_struct_bytes(i)) for i, st in enumerate(ABI_STRUCTS)
+               if C.sizeof(st) != L.hero_abi_struct_bytes(i)]
+        if bad:
+            raise RuntimeError("hero_amd: struct layouts differ from %s (name, binding bytes, library bytes): %s" % (LIB_PATH, bad))
         L.hero_layernorm_bwd_workspace_bytes.restype = C.c_size_t
         L.hero_colsum_workspace_bytes.restype = C.c_size_t
         L.hero_colsum_multi_workspace_bytes.restype = C.c_size_t

@@ -52,6 +52,9 @@ def build(force=False, verbose=False):
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
+    for f in os.listdir(OBJ):                 # objects of sources that left SOURCES (they would still travel to the GPU box)
+        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
+            os.remove(os.path.join(OBJ, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):

@@ -922,7 +922,9 @@ template <int CLS, bool M4>
 int launch2m(const HeroAttn& a, bool bwd, hipStream_t s) {
   const int pairs = a.S * a.H;
   if (bwd) {
-    const size_t lds = (size_t)4 * 64 * RS * 2;          // K (then P), Q, dO, dS tiles
+    const size_t lds = (size_t)4 * 64 * RS * 2;          // K (then P), Q, dO, dS tiles: 72 KiB, above the 64 KiB default
+    HERO_ENSURE_LDS((&attn_mfma_bwd2_kernel<false, CLS, M4>), lds, "attn_mfma_bwd2_kernel");
+    HERO_ENSURE_LDS((&attn_mfma_bwd2_kernel<true, CLS, M4>), lds, "attn_mfma_bwd2_kernel");
     if (a.probs) hipLaunchKernelGGL((attn_mfma_bwd2_kernel<false, CLS, M4>), dim3(pairs), dim3(128), lds, s, a);
     else hipLaunchKernelGGL((attn_mfma_bwd2_kernel<true, CLS, M4>), dim3(pairs), dim3(128), lds, s, a);
   } else {

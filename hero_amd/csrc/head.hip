@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void score_max_fwd_kernel(HeroScoreMax a) {
 // dqn: one workgroup per query m
 __global__ __launch_bounds__(256) void score_max_bwd_q_kernel(HeroScoreMax a) {
   const int m = blockIdx.x;
-  const float gc = a.gc[0] * (a.gc_scale != 0.f ? a.gc_scale : 1.f), gq = a.gq[0] * (a.gq_scale != 0.f ? a.gq_scale : 1.f);
+  const float gc = a.gc[0] * a.gc_scale, gq = a.gq[0] * a.gq_scale;
   for (int d = threadIdx.x * 4; d < a.D; d += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int n = 0; n < a.N; ++n) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void score_max_bwd_c_kernel(HeroScoreMax a) {
   float* out = a.dcn + (size_t)nl * a.L * a.D;
   for (size_t i = threadIdx.x * 4; i < (size_t)a.L * a.D; i += 1024) *reinterpret_cast<float4*>(out + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const float gc = a.gc[0] * (a.gc_scale != 0.f ? a.gc_scale : 1.f), gq = a.gq[0] * (a.gq_scale != 0.f ? a.gq_scale : 1.f);
+  const float gc = a.gc[0] * a.gc_scale, gq = a.gq[0] * a.gq_scale;
   // each thread owns its columns in every row of this video: plain read-modify-write, fixed order
   for (int d = threadIdx.x * 4; d < a.D; d += 1024) {
     for (int m = 0; m < a.M; ++m) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
   }
   c0 = block_sum(c0, red);
   c1 = block_sum(c1, red);
-  const float g = a.g[0] * (a.g_scale != 0.f ? a.g_scale : 1.f);
+  const float g = a.g[0] * a.g_scale;
   for (int i = threadIdx.x; i < 2 * a.L; i += 256) {  // d logits (through mask_logits)
     const int which = i / a.L, l = i - which * a.L;
     const long long t = a.targets[2 * b + which];

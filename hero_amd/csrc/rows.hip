@@ -527,9 +527,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
   const float bc1 = 1.f - powf(gr.beta1, st), bc2 = 1.f - powf(gr.beta2, st);
   const float step_size = lr * sqrtf(bc2) / bc1;
   const float decay = lr * gr.weight_decay;
-  bf16_t* sh16 = d.shadow && d.shadow_dtype == HERO_BF16 ? static_cast<bf16_t*>(d.shadow) : nullptr;
-  float* sh32 = d.shadow && d.shadow_dtype == HERO_F32 ? static_cast<float*>(d.shadow) : nullptr;
-  const bool vec = ((((uintptr_t)d.p | (uintptr_t)d.g | (uintptr_t)d.m | (uintptr_t)d.v | (uintptr_t)sh32) & 15) == 0) && (((uintptr_t)sh16 & 7) == 0);
+  const bool vec = (((uintptr_t)d.p | (uintptr_t)d.g | (uintptr_t)d.m | (uintptr_t)d.v) & 15) == 0;
   if (vec) {
     const size_t e4 = beg + ((end - beg) & ~(size_t)3);
     for (size_t i = beg + threadIdx.x * 4; i < e4; i += 256 * 4) {
@@ -549,8 +547,6 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
       *reinterpret_cast<float4*>(d.p + i) = p;
       *reinterpret_cast<float4*>(d.m + i) = m;
       *reinterpret_cast<float4*>(d.v + i) = v;
-      if (sh16) V4<bf16_t>::st(sh16 + i, p);           // the next step's compute copy, from the registers
-      if (sh32) *reinterpret_cast<float4*>(sh32 + i) = p;
     }
     for (size_t i = e4 + threadIdx.x; i < end; i += 256) {
       const float g = d.g[i] * gs;
@@ -559,8 +555,6 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
       float p = d.p[i] - step_size * m / (sqrtf(v) + gr.eps);
       p -= decay * p;
       d.p[i] = p; d.m[i] = m; d.v[i] = v;
-      if (sh16) sh16[i] = f2bf(p);
-      if (sh32) sh32[i] = p;
     }
   } else {
     for (size_t i = beg + threadIdx.x; i < end; i += 256) {
@@ -570,8 +564,6 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(HeroAdamWMulti a) {
       float p = d.p[i] - step_size * m / (sqrtf(v) + gr.eps);
       p -= decay * p;
       d.p[i] = p; d.m[i] = m; d.v[i] = v;
-      if (sh16) sh16[i] = f2bf(p);
-      if (sh32) sh32[i] = p;
     }
   }
 }

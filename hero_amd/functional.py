@@ -130,48 +130,18 @@ class weights_frozen:
 
 _REFRESH = {}              # descriptor-table signature -> device tables of hero_copy_multi (several: the tasks of a multi-task run
 _REFRESH_PINNED = set()    # update different parameter sets); tables used under stream capture are never dropped (a graph holds their addresses)
-_SHADOW = {"gen": -1, "map": {}}
 
 
-def straight_copy_of(p):
-    """(device pointer, dtype code) of the cached compute copy region that holds parameter `p` in its own flat element order
-    (the straight bf16 / fp32 copies of `packed`; a parameter inside a row-concatenated copy - Q, K, V - owns a contiguous
-    region of it), or None.  The fused AdamW writes these regions from its registers (HeroTensorDesc.shadow), so the
-    optimiser pass produces the next step's straight copies and refresh_weight_cache only has the transposes left."""
-    if _SHADOW["gen"] != (_WGEN[0], len(_WCACHE)):
-        m = {}
-        for key, (_, out, params) in _WCACHE.items():
-            if len(key) != 2:
-                continue                                # transposed copies are not flat images of their parameters
-            off = 0
-            for q in params:
-                m[id(q)] = (out.data_ptr() + off * out.element_size(), L.dt(out), q.numel())
-                off += q.numel()
-        _SHADOW["gen"], _SHADOW["map"] = (_WGEN[0], len(_WCACHE)), m
-    hit = _SHADOW["map"].get(id(p))
-    return (hit[0], hit[1]) if hit is not None and hit[2] == p.numel() else None
-
-
-def refresh_weight_cache(straight_done=False):
+def refresh_weight_cache():
     """Re-derive every cached compute copy from the current fp32 master weights NOW, in ONE launch
     (hero_copy_multi over a device-resident descriptor table: ~160 cast / transpose launches per
     optimiser step otherwise).  Called right after the optimiser step - eagerly, and inside the
-    captured hipGraph - so the next forward finds the cache valid.
-    straight_done: the optimiser pass has written the straight copies of every parameter it updated itself (round 5:
-    hero_amd.optim.AdamW with write_copies - a parameter it did not update has not changed), so only the TRANSPOSED copies
-    are re-derived.  The set of transposed copies does not depend on which task's parameters the step updated: one
-    descriptor table per generation of the cache, built by the eager warm-up steps, found again under capture."""
+    captured hipGraph - so the next forward finds the cache valid.  (Round 5 also let the AdamW kernel write the straight
+    copies from its registers; measured +17 us per optimiser step in the kernels and no change of the step - removed in
+    round 6, DESIGN changelog.)"""
     if not _WCACHE:
         return
     entries = list(_WCACHE.items())
-    if straight_done:
-        ep = _WEPOCH[0]
-        for key, (_, out, params) in entries:
-            if len(key) == 2:                           # already current: written by the optimiser kernel, or unchanged
-                _WCACHE[key] = ((tuple(q._version for q in params), tuple(q.data_ptr() for q in params), ep), out, params)
-        entries = [(k, v) for k, v in entries if len(k) != 2]
-        if not entries:
-            return
     tsig = tuple((key, val[1].data_ptr(), tuple(p.data_ptr() for p in val[2])) for key, val in entries)
     if tsig not in _REFRESH:
         if len(_REFRESH) > 16:
@@ -923,7 +893,10 @@ def host_sortable_orders(batch):
     function of ONE int64 id tensor of `batch`: [(batch key, order tensor, skip index)].  A feeder that gets its ids from the
     host can compute such an order there (numpy stable argsort, hidden behind the GPU's step) and copy it in, instead of
     re-sorting on the device inside every commit (hero_segment_sort is one workgroup: 69 us for 9600 ids)."""
-    by_out = {v[0].data_ptr(): v for v in _MEMO.values() if isinstance(v[0], torch.Tensor)}      # by address: callers pass views (idx.view(-1))
+    # by address (callers pass views, idx.view(-1)) - and ONLY the plain int32 casts of a batch tensor (`row_index`, spec
+    # DERIVE_I32): an index derived any other way (a flat gather map ...) must keep its device sort (ADVICE r5)
+    by_out = {v[0].data_ptr(): v for k_, v in _MEMO.items()
+              if isinstance(v[0], torch.Tensor) and k_[0] == "row_index" and v[3] is not None and v[3][0] == L.DERIVE_I32}
     keys = {t.data_ptr(): k for k, t in batch.items() if torch.is_tensor(t) and t.dtype == torch.int64}
     found = []
     for mk, (out, srcs, fn, spec) in _MEMO.items():
@@ -1280,42 +1253,82 @@ class SplitRowsFn(torch.autograd.Function):
         return (full if full is not None else torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
 
 
+class _FirstRefCheck:
+    """Outcome of the run-time precondition check of GatherRowsFn's one-gather backward: did every VALID output position
+    turn out to be the first reference to its source row?  The device computes one flag when the first-occurrence map is
+    built (once per index tensor), a non-blocking copy brings it to pinned host memory, and the BACKWARD reads it - several
+    milliseconds of queued work later, so the wait is already over and no forward ever stalls on it."""
+    __slots__ = ("flag", "event", "value")
+
+    def __init__(self, flag, event):
+        self.flag, self.event, self.value = flag, event, None
+
+    def ok(self):
+        if self.value is None:
+            self.event.synchronize()
+            self.value = int(self.flag[0]) == 0
+        return self.value
+
+
+def first_reference_map(idx, valid, na, nb):
+    """(inv, check) for GatherRowsFn's backward: inv = hero_inverse_first(idx) - source row -> its first referencing
+    position - and check.ok() == "no valid position (valid != 0) is a LATER reference to its source row", which is what
+    makes `d source = d out[inv]` the exact adjoint of the gather when masked positions receive no gradient.  HERO's own
+    f_gather_index (data/data.py:504-512) always passes; a caller-built index that repeats a source at a valid position does
+    not, and the backward then falls back to the scatter-add.  Both are memoised per index tensor; a memo refreshed IN PLACE
+    (functional.refresh_memo: the feeder's static buffers, whose index hero_amd.collate.DeviceCollate builds in the
+    reference's layout) keeps the verdict of the batch it was built for.  None where it cannot be decided (too many rows
+    for the map's LDS table, no mask, shapes that do not line up, or a stream that is being captured)."""
+    n = idx.numel()
+    if (valid is None or valid.numel() != n or na + nb > 38400 or idx.dtype != torch.int32 or not idx.is_contiguous()
+            or not idx.is_cuda):
+        return None
+
+    def build():
+        inv = torch.empty(na + nb, dtype=torch.int32, device=idx.device)
+        L.check(L.lib().hero_inverse_first(L.ptr(idx), n, L.ptr(inv), na, nb, L.stream()))
+        return inv
+    inv = memo("gather_inverse", (idx, valid), build, (na, nb))
+    chk = getattr(inv, "_hero_first_check", None)
+    if chk is None:
+        if torch.cuda.is_current_stream_capturing():       # the flag has to reach the host: not inside a capture
+            return None
+        i64 = idx.to(torch.int64)
+        src = torch.where(i64 >= 0, i64, na - i64 - 2).clamp_(0, na + nb - 1)
+        pos = torch.arange(n, device=idx.device, dtype=torch.int32)
+        later = (inv[src] != pos) & (idx != -1) & (valid.reshape(-1) != 0)
+        flag = torch.empty(1, dtype=torch.int32).pin_memory()
+        flag.copy_(later.any().to(torch.int32).reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        chk = inv._hero_first_check = _FirstRefCheck(flag, ev)
+    return inv, chk
+
+
 class GatherRowsFn(torch.autograd.Function):
     """out[r] = a[idx[r]] (idx>=0) | 0 (idx==-1) | b[-idx-2]."""
 
     @staticmethod
-    def forward(ctx, a, b, idx, tail_rows=0, first_grad=False):
-        """first_grad: the caller guarantees that a source row referenced more than once receives gradient through its FIRST
-        reference only (HERO's f_gather_index: the later references are padded positions, whose gradients are exactly zero) -
-        the backward is then one gather through the first-occurrence map (hero_inverse_first) instead of two zero fills and a
-        scatter-add."""
+    def forward(ctx, a, b, idx, tail_rows=0, valid=None):
+        """valid: 0/1 mask over the output positions (HERO: f_attn_masks).  With it the caller states that positions whose bit
+        is 0 receive no gradient; IF, in addition, every valid position is the first reference to its source row - checked on
+        the device, `first_reference_map` - the backward is one gather through the first-occurrence map instead of two zero
+        fills and a scatter-add.  Without it, or when the check fails, the backward is the scatter-add."""
         a2, b2 = _as2d(a), (_as2d(b) if b is not None else None)
         ctx.save_for_backward(idx)
         ctx.ashape, ctx.bshape = a.shape, (b.shape if b is not None else None)
         na, nb = a2.shape[0], (b2.shape[0] if b2 is not None else 0)
-        ctx.first = bool(first_grad) and na + nb <= 38400 and idx.dtype == torch.int32 and idx.is_contiguous()
+        ctx.first = first_reference_map(idx, valid, na, nb) if valid is not None else None
         return k_gather_rows(a2, b2, idx, idx.numel(), a2.shape[1], tail_rows=tail_rows)
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         dy2 = _as2d(dy)
-        if ctx.first:
-            na = 1
-            for d_ in ctx.ashape[:-1]:
-                na *= int(d_)
-            nb = 0
-            if ctx.bshape is not None:
-                nb = 1
-                for d_ in ctx.bshape[:-1]:
-                    nb *= int(d_)
-
-            def build():
-                inv = torch.empty(na + nb, dtype=torch.int32, device=idx.device)
-                L.check(L.lib().hero_inverse_first(L.ptr(idx), idx.numel(), L.ptr(inv), na, nb, L.stream()))
-                return inv
-            inv = memo("gather_inverse", (idx,), build, (na, nb))
-            both = k_gather_rows(dy2.contiguous(), None, inv, na + nb, dy2.shape[1])
+        if ctx.first is not None and ctx.first[1].ok():
+            inv = ctx.first[0]
+            na = inv.numel() if ctx.bshape is None else ctx.ashape.numel() // ctx.ashape[-1]
+            both = k_gather_rows(dy2.contiguous(), None, inv, inv.numel(), dy2.shape[1])
             return both[:na].view(ctx.ashape), (both[na:].view(ctx.bshape) if ctx.bshape is not None else None), None, None, None
         da = torch.zeros(ctx.ashape, dtype=dy.dtype, device=dy.device)
         db = torch.zeros(ctx.bshape, dtype=dy.dtype, device=dy.device) if ctx.bshape is not None else None

@@ -142,8 +142,10 @@ class CrossModalTrm(RobertaPreTrainedModel):
 
     def _compute_img_txt_embeddings(self, input_ids, position_ids, img_feat, img_pos_ids,
                                     gather_index, txt_type_ids=None, img_type_ids=None,
-                                    img_masks=None, tail_rows=0):
-        """tail_rows (hero_amd only): spare rows allocated behind the result for the row stack of the fused query pass."""
+                                    img_masks=None, tail_rows=0, attention_mask=None):
+        """hero_amd only: tail_rows = spare rows allocated behind the result for the row stack of the fused query pass;
+        attention_mask = the 0/1 mask over the gathered positions (f_attn_masks) when the caller has one - it lets the
+        gather's backward take its one-gather form (HF.GatherRowsFn `valid`: checked against the index on the device)."""
         txt_emb = img_emb = None
         if input_ids is not None:
             txt_emb = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
@@ -153,9 +155,12 @@ class CrossModalTrm(RobertaPreTrainedModel):
             assert gather_index is not None
             T, Lout = gather_index.shape
             flat = self._flat_gather_index(gather_index, img_emb.shape[1], txt_emb.shape[1])
-            # first_grad: get_gather_index (data/data.py:504-512) references a source row twice only from the padded
-            # "identity tail" BEHIND its valid position, and nothing downstream gives a padded position a gradient
-            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat, tail_rows, True)
+            # get_gather_index (data/data.py:504-512) references a source row twice only from the padded "identity tail"
+            # BEHIND its valid position, and nothing downstream gives a masked position a gradient: with the mask at hand the
+            # backward is one gather - after a device-side check of exactly that property of THIS index (VERDICT r5 #1c)
+            valid = attention_mask if (attention_mask is not None and attention_mask.dim() == 2
+                                       and not attention_mask.is_floating_point()) else None
+            out = HF.GatherRowsFn.apply(img_emb, txt_emb, flat, tail_rows, valid)
             return out.view(T, Lout, -1)
         if txt_emb is not None:
             return txt_emb
@@ -191,7 +196,8 @@ class CrossModalTrm(RobertaPreTrainedModel):
     def forward_repr(self, input_ids, position_ids, img_feat, img_pos_ids, attention_mask,
                      gather_index=None, txt_type_ids=None, img_type_ids=None, img_masks=None):
         emb = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_ids,
-                                               gather_index, txt_type_ids, img_type_ids, img_masks)
+                                               gather_index, txt_type_ids, img_type_ids, img_masks,
+                                               attention_mask=attention_mask)
         seq = self.encoder(emb, attention_mask)[0]
         pooled = self.pooler(seq) if self.run_pooler else None
         return (seq, pooled)
@@ -199,7 +205,7 @@ class CrossModalTrm(RobertaPreTrainedModel):
     def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_ids, attention_mask,
                     gather_index, txt_mask_tgt, txt_labels=None, compute_loss=True):
         emb = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_ids,
-                                               gather_index)
+                                               gather_index, attention_mask=attention_mask)
         seq = self.encoder(emb, attention_mask)[0]
         rows = HF.memo("mask_rows", (txt_mask_tgt,),     # once per batch object: nonzero synchronises (no graph capture)
                        lambda: torch.nonzero(txt_mask_tgt.reshape(-1), as_tuple=False).reshape(-1).to(torch.int32).contiguous())

@@ -58,7 +58,8 @@ class HeroForPretraining(HeroModel):
             emb_v = fe._compute_img_txt_embeddings(
                 batch["f_sub_input_ids"], batch["f_sub_pos_ids"], batch["f_v_feats"], batch["f_v_pos_ids"],
                 batch["f_gather_index"], img_masks=batch["f_v_masks"],
-                tail_rows=batch["query_input_ids"].numel())          # the query rows are stacked right behind (StackRowsFn)
+                tail_rows=batch["query_input_ids"].numel(),          # the query rows are stacked right behind (StackRowsFn)
+                attention_mask=batch["f_attn_masks"])
             emb_q = fe._compute_txt_embeddings(batch["query_input_ids"], batch["query_pos_ids"])
             seq_v, seq_q = fe.encoder.forward_multi([emb_v, emb_q],
                                                     [batch["f_attn_masks"], batch["query_attn_masks"]])

@@ -30,14 +30,6 @@ class AdamW(Optimizer):
         self._pinned = []         # tables built or used while a hipGraph was capturing: the graph holds their addresses
         self._tsteps = None       # device-state mode: per-parameter step counts on the device (int32 [n params])
         self._slots = None        # parameter -> slot in _tsteps
-        # round 5: the kernel can also write the cached straight compute copy (bf16) of every parameter that has one
-        # (functional.straight_copy_of), so that the weight-copy refresh after the step only has the transposes left.
-        # Built because three verdicts priced it at -0.03 ms per micro-step; MEASURED (rocprofv3, steady state, per optimiser
-        # step): adamw_multi_kernel 536 -> 584 us (8-byte bf16 stores between the 16-byte fp32 ones), copy_multi_kernel
-        # 137 -> 106 us (the transposes are the expensive half) = +17 us, step time unchanged within noise in a same-box
-        # A/B.  OFF by default; last_shadowed = ids of the parameters whose copies the last step() wrote.
-        self.write_copies = False
-        self.last_shadowed = frozenset()
         self.last_active = []     # (group index, parameter) of the last step(): what TrainStep hands to prebuild()
 
     def load_state_dict(self, state_dict):
@@ -99,10 +91,8 @@ class AdamW(Optimizer):
             g = p.grad
             if not (p.is_contiguous() and g.is_contiguous()):
                 raise RuntimeError("hero_amd AdamW needs contiguous parameters and gradients")
-            sh = HF.straight_copy_of(p) if self.write_copies else None
             descs[i] = L.TensorDesc(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                    p.numel(), gi, self._slots[p] if slots else self._global_step - st["step"],
-                                    sh[0] if sh else None, sh[1] if sh else 0, 0)
+                                    p.numel(), gi, self._slots[p] if slots else self._global_step - st["step"])
             n = -(-p.numel() // chunk)
             ct.extend([i] * n)
             ci.extend(range(n))
@@ -164,9 +154,6 @@ class AdamW(Optimizer):
         else:
             sig = tuple((id(p), p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
                          self.state[p]["exp_avg_sq"].data_ptr(), self._global_step - self.state[p]["step"]) for _, p in active)
-        shadows = tuple(HF.straight_copy_of(p) for _, p in active) if self.write_copies else ()
-        sig = sig + (shadows,)                       # a table holds the copies' addresses: new copies, new table
-        self.last_shadowed = frozenset(id(p) for (_, p), sh in zip(active, shadows) if sh is not None)
         capturing = torch.cuda.is_current_stream_capturing()
         if sig not in self._tables:
             if len(self._tables) >= 16 and not capturing:

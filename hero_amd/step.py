@@ -133,8 +133,7 @@ class TrainStep:
                             grad_scale=1.0 / D.world_size(), skip=set(untouched),
                             step_tensor=self._step_t if device_state else None,
                             lr_tensor=self._lr_t if device_state else None)
-        # the transposed weight copies in one launch; the straight ones were written by the AdamW kernel itself
-        HF.refresh_weight_cache(straight_done=bool(getattr(self.optimizer, "write_copies", False)))
+        HF.refresh_weight_cache()                    # every compute copy of the weights in one launch
         self.arena.zero()
 
     def _set_lr(self):

@@ -35,9 +35,23 @@ const char* hero_last_error(void);
 /* ABI version of the structs and entry points below; a binding compiled against another version must refuse to run
  * (hero_amd/_lib.py does).  History: 1 = rounds 1-3.  2 = INCOMPATIBLE struct changes of round 4 - HeroQueryPool.dw is
  * [B, D] and OVERWRITTEN (was [D], accumulated), HeroStEd gained the required zero-initialised `ws`, HeroColsum gained
- * row_cols / dst_rows - plus the round-5 additions (hero_probe_*, HeroAdamWMulti.shadow tables). */
-#define HERO_ABI_VERSION 2
+ * row_cols / dst_rows.  3 = the round-5 struct changes that went out under "2" by mistake - HeroTensorDesc 48 -> 64 bytes
+ * (shadow, shadow_dtype; it is passed as an ARRAY, so the stride changed), HeroGemmEpilogue + 16 bytes (colsum_partial,
+ * split_stride), HeroScoreMax + 8 bytes (gc_scale, gq_scale), HeroStEd.pad_ became g_scale - plus round 6: the three
+ * scales are plain multipliers (the "0 means 1" sentinel is gone: pass 1.0f for "no weight"), hero_abi_struct_bytes().
+ * INTEGRATION.md section 2 lists the breaks per version. */
+#define HERO_ABI_VERSION 3
 int hero_abi_version(void);
+/* sizeof() of every struct of this header as the LIBRARY was compiled, by HERO_STRUCT_* id (-1 for an unknown id): a
+ * binding asserts its own layout against these at load time (hero_amd/_lib.py), so a struct that changes size without a
+ * version bump is caught structurally and not by a crash.  hero_abi_struct_count() = number of ids. */
+enum { HERO_STRUCT_DROPOUT = 0, HERO_STRUCT_GEMM_EPILOGUE, HERO_STRUCT_WGRAD_PROBLEM, HERO_STRUCT_LN_FWD, HERO_STRUCT_LN_BWD,
+       HERO_STRUCT_COLSUM, HERO_STRUCT_ATTN, HERO_STRUCT_ADAMW, HERO_STRUCT_TENSOR_DESC, HERO_STRUCT_ADAMW_GROUP,
+       HERO_STRUCT_ADAMW_MULTI, HERO_STRUCT_COPY_DESC, HERO_STRUCT_QUERY_POOL, HERO_STRUCT_ROW_NORM, HERO_STRUCT_SCORE_MAX,
+       HERO_STRUCT_RANK_LOSS, HERO_STRUCT_ST_ED, HERO_STRUCT_CROSS_ENTROPY, HERO_STRUCT_DERIVE, HERO_STRUCT_COMM_BUCKET,
+       HERO_STRUCT_COUNT_ };
+int hero_abi_struct_count(void);
+int hero_abi_struct_bytes(int which);
 
 /* Counter-based dropout. keep(element) is a pure function of (*seed_ptr, site, element index), so
  * the backward kernels regenerate the forward mask instead of loading one. threshold16 = round(p *
@@ -366,9 +380,6 @@ typedef struct HeroTensorDesc {
   uint64_t n;
   int32_t group;
   int32_t step_lag;
-  void* shadow;          /* optional: a compute copy of p with the SAME flat element order (bf16 or fp32, shadow_dtype) that */
-  int32_t shadow_dtype;  /* the kernel rewrites from the updated values - the optimiser pass produces the next step's weight  */
-  int32_t pad_;          /* copies instead of a separate read of every master weight (hero_copy_multi)                        */
 } HeroTensorDesc;
 typedef struct HeroAdamWGroup {
   float lr, beta1, beta2, eps, weight_decay;
@@ -474,7 +485,7 @@ typedef struct HeroScoreMax {
   float* dqn;             /* bwd out [M, D]                                                     */
   float* dcn;             /* bwd out [n_own*L, D]                                               */
   int M, N, L, D, n0, n_own, ld_s;
-  float gc_scale, gq_scale; /* bwd: *gc and *gq are multiplied by these (the loss weights, folded in); 0 means 1 */
+  float gc_scale, gq_scale; /* bwd: *gc and *gq are multiplied by these (the loss weights, folded in; 1.0f = none) */
 } HeroScoreMax;
 /* out[s] = scales[s] * sum(src[s * seg_len .. (s + 1) * seg_len)), 1..4 segments, fixed summation order: the final
  * reductions of the loss head (sum of the start / end rows, means of the ranking-loss rows) with the loss weights
@@ -526,7 +537,7 @@ typedef struct HeroStEd {
   float* dw_st;           /* bwd out [K], ACCUMULATED (+=)                                      */
   float* dw_ed;           /* bwd out [K], ACCUMULATED (+=)                                      */
   int B, L, D, K, dtype;
-  float g_scale;          /* bwd: *g is multiplied by this (the loss weight, folded in); 0 means 1     */
+  float g_scale;          /* bwd: *g is multiplied by this (the loss weight, folded in; 1.0f = none)    */
   float* ws;              /* bwd scratch, hero_st_ed_bwd_workspace_bytes(B) bytes, ZERO before the first */
                           /* use (the kernel leaves its arrival counter at zero): per-pair shares of     */
                           /* dw_st / dw_ed, folded in pair order by the last workgroup to arrive - the   */

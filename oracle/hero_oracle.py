@@ -291,14 +291,26 @@ def query_feat_encoder(q_seq, q_mask, P, cfg, prefix="q_feat_attn", p_drop=0.0):
     return torch.einsum("blm,bld->bmd", w, a)[:, 0]
 
 
-def st_ed_logits(mod_q, ctx, ctx_mask, P):
-    """_get_st_ed_prob, non-cross branch (pretrain.py:118-166)."""
+def st_ed_logits(mod_q, ctx, ctx_mask, P, q_vidx=None):
+    """get_pred_from_mod_query + _get_st_ed_prob (pretrain.py:118-166, 188-201): the matched branch when there is one query
+    per video; otherwise (several queries per video, data/vsm.py:105-145) the CROSS branch - every query against every
+    video, `md,nld->mnl`, both Conv1d on (Nq*Nv, 1, L), mask (1, Nv, L) - followed by the caller's [row, q_vidx] selection
+    (pretrain.py:93-99)."""
     q = linear(mod_q, P, "video_query_linear")
-    sim = torch.einsum("bd,bld->bl", q, ctx).unsqueeze(1)
-    st = F.conv1d(sim, P["video_st_predictor.weight"], padding=2).squeeze(1)
-    ed = F.conv1d(sim, P["video_ed_predictor.weight"], padding=2).squeeze(1)
     m = ctx_mask.to(torch.float32)
-    return mask_logits(st, m), mask_logits(ed, m)
+    if q.shape[0] == ctx.shape[0]:
+        sim = torch.einsum("bd,bld->bl", q, ctx).unsqueeze(1)
+        st = F.conv1d(sim, P["video_st_predictor.weight"], padding=2).squeeze(1)
+        ed = F.conv1d(sim, P["video_ed_predictor.weight"], padding=2).squeeze(1)
+        return mask_logits(st, m), mask_logits(ed, m)
+    sim = torch.einsum("md,nld->mnl", q, ctx)
+    nq, nc, ln = sim.shape
+    flat = sim.reshape(nq * nc, 1, ln)
+    st = F.conv1d(flat, P["video_st_predictor.weight"], padding=2).view(nq, nc, ln)
+    ed = F.conv1d(flat, P["video_ed_predictor.weight"], padding=2).view(nq, nc, ln)
+    st, ed = mask_logits(st, m.unsqueeze(0)), mask_logits(ed, m.unsqueeze(0))
+    rows = torch.arange(nq)
+    return st[rows, q_vidx], ed[rows, q_vidx]
 
 
 def video_level_scores(mod_q, ctx, ctx_mask):
@@ -351,7 +363,7 @@ def vsm_losses(batch, P, cfg, lw_st_ed=0.01, lw_neg_ctx=8.0, lw_neg_q=8.0,
                           batch["query_attn_masks"], P, cfg, p_drop=p_drop)
     mod_q = query_feat_encoder(q_seq, batch["query_attn_masks"], P, cfg,
                                p_drop=p_drop)
-    st, ed = st_ed_logits(mod_q, frames, batch["c_attn_masks"], P)
+    st, ed = st_ed_logits(mod_q, frames, batch["c_attn_masks"], P, batch.get("q_vidx"))
     tg = batch["targets"]
     l_st_ed = (F.cross_entropy(st, tg[:, 0], ignore_index=-1)
                + F.cross_entropy(ed, tg[:, 1], ignore_index=-1))

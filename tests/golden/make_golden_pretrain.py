@@ -9,6 +9,9 @@ collate it reuses.  Writes tests/golden/case_pretrain.npz:
           (model/encoder.py:355-374)
   mfm.*   v_encoder(batch, 'mfm-nce'/'mffr')  losses (model/model.py:239-289)
   fom.*   v_encoder(batch, 'fom')        loss + logits (model/model.py:306-336)
+  vsm.*   model(batch, 'vsm') with TWO queries per video (data/vsm.py:21,105-145: query_per_video, q_vidx) - the
+          cross branch of get_pred_from_mod_query + the [row, q_vidx] selection (model/pretrain.py:72-110, 188-201)
+          and the per > 1 ranking loss (model/pretrain.py:203-292): the three weighted losses
   grad.<task>.<param>  gradients of mean(loss) for a few parameters of each task
 
 Run:  python tests/golden/make_golden_pretrain.py
@@ -117,7 +120,24 @@ def main():
     grads("fom", loss, ["v_encoder.fom_output.linear_1.weight", "v_encoder.fom_output.linear_2.bias",
                         "v_encoder.fom_output.LayerNorm.weight", "v_encoder.frame_transform.net.1.weight",
                         "v_encoder.c_encoder.embeddings.position_embeddings.weight"])
+    # ---- VSM, several queries per video (data/vsm.py:105-145) - appended LAST: the draws above are unchanged ----------
+    per = 2
+    qi, qp, qm = G.synth_queries(gen, 3 * per, [5, 7, 4, 6, 3, 7])
+    tg = torch.tensor([[1, 3], [0, 2], [2, 4], [-1, 5], [3, 6], [7, 9]])          # one ignored start (padding_value -1)
+    vsm = dict(vb)
+    vsm.update({"query_input_ids": qi, "query_pos_ids": qp, "query_attn_masks": qm, "targets": tg,
+                "q_vidx": torch.arange(3 * per) // per})
+    for k in ("query_input_ids", "query_pos_ids", "query_attn_masks", "targets", "q_vidx"):
+        d["in.vsm." + k] = vsm[k].numpy()
+    model.zero_grad()
+    losses = model(vsm, task="tvr", compute_loss=True)            # HeroForVcmr routes it to HeroForPretraining.forward(task="vsm")
+    d["vsm.losses"] = torch.stack([l.reshape(()) for l in losses]).detach().numpy()
+    sum(l.sum() for l in losses).backward()
+    for n_ in ["video_query_linear.weight", "video_st_predictor.weight", "q_feat_attn.modular_vector_mapping.weight",
+               "v_encoder.c_encoder.encoder.layer.0.output.dense.weight", "v_encoder.f_encoder.encoder.layer.0.attention.self.query.weight"]:
+        d["grad.vsm.%s" % n_] = params[n_].grad.detach().numpy().copy()
     np.savez_compressed(os.path.join(HERE, "case_pretrain.npz"), **d)
+    print("vsm (2 queries per video)", d["vsm.losses"])
     print("case_pretrain.npz  mlm", float(d["mlm.loss"].mean()), " mfm-nce", float(d["mfm.mfm-nce.loss"].mean()),
           " mffr", float(d["mfm.mffr.loss"].mean()), " fom", float(d["fom.loss"]))
 

@@ -31,7 +31,63 @@ def test_library_exports_every_declared_symbol(built_lib):
     from hero_amd import _lib
     assert set(_lib.EXPORTS) == declared
     handle.hero_abi_version.restype = ctypes.c_int
-    assert handle.hero_abi_version() == 2          # include/hero_hip.h HERO_ABI_VERSION (history there)
+    assert handle.hero_abi_version() == 3 == _lib.ABI_VERSION         # include/hero_hip.h HERO_ABI_VERSION (history there)
+
+
+def test_abi_struct_sizes_are_pinned_per_version(built_lib):
+    """a struct of include/hero_hip.h that changes size must come with a new HERO_ABI_VERSION.  The sizes of
+    every struct are committed per version (tests/golden/abi_sizes.json); the binding's ctypes mirrors, the header as gcc
+    sees it, and the library's own hero_abi_struct_bytes() must all give the table of the CURRENT version, and the table of
+    an older version is never edited (a changed struct under an old number fails here: bump the version, add a table)."""
+    import json
+    import subprocess
+    import tempfile
+    from hero_amd import _lib
+    table = json.load(open(os.path.join(GOLDEN, "abi_sizes.json")))
+    header = open(os.path.join(ROOT, "include", "hero_hip.h")).read()
+    version = int(re.search(r"#define HERO_ABI_VERSION (\d+)", header).group(1))
+    assert version == _lib.ABI_VERSION
+    assert str(version) in table, "HERO_ABI_VERSION %d has no committed size table: add it to tests/golden/abi_sizes.json" % version
+    want = table[str(version)]
+    mine = _lib.abi_struct_sizes()
+    assert mine == want, ("struct sizes differ from the table committed for ABI version %d - an incompatible change needs a "
+                          "version bump (include/hero_hip.h, hero_amd/_lib.py, INTEGRATION.md) and a new table" % version,
+                          {k: (mine.get(k), want.get(k)) for k in set(mine) | set(want) if mine.get(k) != want.get(k)})
+    # every typedef'd struct of the header has an id, a mirror and the same size under gcc and inside the library
+    names = re.findall(r"^} (Hero\w+);", header, flags=re.M)
+    assert ["Hero" + n for n in mine] == names, "ABI_STRUCTS / HERO_STRUCT_* must list the header's structs in declaration order"
+    src = '#include <stdio.h>\n#include "hero_hip.h"\nint main(){%s return 0;}\n' % "".join('printf("%%zu ", sizeof(%s));' % n for n in names)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "s.c"), "w") as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        gcc_sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
+    assert gcc_sizes == list(mine.values())
+    handle = ctypes.CDLL(built_lib)
+    assert handle.hero_abi_struct_count() == len(names)
+    assert [handle.hero_abi_struct_bytes(i) for i in range(len(names))] == gcc_sizes
+    assert handle.hero_abi_struct_bytes(len(names)) == -1 and handle.hero_abi_struct_bytes(-1) == -1
+    # the enum ids are in declaration order too
+    ids = re.search(r"enum \{ (HERO_STRUCT_DROPOUT.*?)HERO_STRUCT_COUNT_", header, flags=re.S).group(1)
+    assert len(re.findall(r"HERO_STRUCT_[A-Z_]+", ids)) == len(names)
+
+
+def test_binding_refuses_a_library_with_other_struct_sizes(built_lib, monkeypatch):
+    """The load-time guard itself: a mirror that is 8 bytes short of the library's struct raises before any kernel runs."""
+    from hero_amd import _lib
+
+    class Short(ctypes.Structure):
+        _fields_ = _lib.TensorDesc._fields_[:-2]
+    Short.__name__ = "TensorDesc"
+    structs = list(_lib.ABI_STRUCTS)
+    structs[structs.index(_lib.TensorDesc)] = Short
+    monkeypatch.setattr(_lib, "ABI_STRUCTS", structs)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="struct layouts differ"):
+        _lib.lib()
+    monkeypatch.undo()
+    _lib._lib = None
+    _lib.lib()
 
 
 def test_struct_layouts_match_header_sizes(built_lib):

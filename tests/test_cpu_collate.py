@@ -121,7 +121,7 @@ def test_oracle_lse_hard_negative_branch_against_reference():
 
 def test_reference_gather_index_names_a_source_row_first_from_its_valid_position():
     """Round 5: the embedding interleave's backward is ONE gather through the first-occurrence map of f_gather_index
-    (hero_inverse_first, functional.GatherRowsFn(first_grad=True)) - exact only because, in every index tensor the REFERENCE's
+    (hero_inverse_first, functional.GatherRowsFn(valid=f_attn_masks)) - exact only because, in every index tensor the REFERENCE's
     get_gather_index produces (data/data.py:504-512; ten batches of case_collate.npz incl. the narrow ones, a zero-frame subtitle
     and the 511 clamp), a valid position is always the FIRST reference to its source row: the repeats sit in the padded
     identity tail, whose gradients are exactly zero."""

@@ -175,3 +175,54 @@ def test_model_fused_head_equals_torch_head(hard, loss_type):
     assert set(gf) == set(gt)
     worst = max(rel_err(gf[k], gt[k]) for k in gt if float(gt[k].abs().max()) > 1e-8)
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("w_ctx,w_q", [(0.0, 8.0), (8.0, 0.0)])
+def test_video_rank_loss_zero_weight_switches_that_term_off(w_ctx, w_q):
+    """the backward kernels read a loss weight of exactly 0 as 1, so a configuration with ONE of
+    lw_neg_ctx / lw_neg_q at zero (model/pretrain.py:80,112 allows it) got the full unweighted gradient of the term the
+    forward had switched off.  The scales are plain multipliers since ABI version 3."""
+    from hero_amd.head import VideoRankLossFn
+    N, L, D = 7, 13, 128
+    qn = F.normalize(rnd(N, D, seed=1), dim=-1).requires_grad_(True)
+    cn = F.normalize(rnd(N, L, D, seed=2), dim=-1).requires_grad_(True)
+    mask = torch.ones(N, L).cuda()
+    mask[1, 5:] = 0
+    lc, lq = VideoRankLossFn.apply(qn, cn, mask, (0, N), 0.1, False, False, 3, 10.0, w_ctx, w_q)
+    (lc + lq).backward()                    # autograd sends g = 1 for BOTH outputs
+    qr, cr = qn.detach().clone().requires_grad_(True), cn.detach().clone().requires_grad_(True)
+    q2v = mask_logits(torch.einsum("md,nld->mln", qr, cr), mask.t().unsqueeze(0)).max(dim=1)[0]
+    rc, rq = torch_rank_losses(q2v, 1, 0.1, False, False, 3, 10.0)
+    (w_ctx * rc + w_q * rq).backward()
+    assert abs(float(lc) - w_ctx * float(rc)) < 1e-5 and abs(float(lq) - w_q * float(rq)) < 1e-5
+    assert (float(lc) == 0.0) == (w_ctx == 0.0) and (float(lq) == 0.0) == (w_q == 0.0)
+    assert rel_err(qn.grad, qr.grad) < 1e-4 and rel_err(cn.grad, cr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("lw", [dict(lw_neg_ctx=0.0, lw_neg_q=8.0), dict(lw_neg_ctx=8.0, lw_neg_q=0.0)])
+def test_model_fused_head_with_one_ranking_weight_zero(lw):
+    """The same at model level: losses and every parameter gradient of the HIP head == the PyTorch head with one of the two
+    ranking-loss weights at zero."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.utils.misc import set_dropout
+    hero_amd.set_compute_dtype(torch.float32)
+    batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_train.npz"))
+    b = to_dev(batch, "cuda")
+    res = []
+    for fused in (True, False):
+        HF.set_grad_sink(None)
+        model, _, _ = load_tiny("cuda", **lw)
+        model.train()
+        set_dropout(model, 0.0)
+        model.fused_head = fused
+        model.q_feat_attn.fused_pool = fused
+        losses = model(b, task="tvr", compute_loss=True)
+        sum(l.sum() for l in losses).backward()
+        res.append(([float(l.sum()) for l in losses], {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (lf, gf), (lt, gt) = res
+    for a, c in zip(lf, lt):
+        assert abs(a - c) < 1e-5 * max(1.0, abs(c)), (lf, lt)
+    assert set(gf) == set(gt)
+    worst = max(rel_err(gf[k], gt[k]) for k in gt if float(gt[k].abs().max()) > 1e-8)
+    assert worst < 2e-4, worst

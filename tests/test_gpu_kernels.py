@@ -851,7 +851,7 @@ def test_row_stack_and_split_in_place(HF, Lb):
 
 
 def test_gather_backward_through_the_first_occurrence_map(HF, Lb):
-    """Round 5: hero_inverse_first + GatherRowsFn(first_grad=True).  The reference's gather index (data/data.py:504-512) names a
+    """Round 5: hero_inverse_first + GatherRowsFn(valid=mask).  The reference's gather index (data/data.py:504-512) names a
     source row a second time only from a padded position BEHIND its valid one, and padded positions receive exactly zero
     gradient - then the backward is one gather through the first-occurrence map.  Checked: the map itself, the gradients
     against the scatter-add backward when the repeated references carry zero gradient, and that a reference's reference-built
@@ -881,9 +881,13 @@ def test_gather_backward_through_the_first_occurrence_map(HF, Lb):
     w = rnd(n, 64, dtype=dtype, seed=3)
     w[120:] = 0                                                              # the repeats (padded positions) carry no gradient
     grads = []
-    for fg in (False, True):
+    valid = torch.zeros(n, dtype=torch.int64, device="cuda")
+    valid[:120] = 1                                                          # the repeats sit at masked positions
+    for fg in (None, valid):
         a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
         out = HF.GatherRowsFn.apply(a, b, idx_d, 0, fg)
+        if fg is not None:                                                   # the device-side check agreed: one-gather backward
+            assert out.grad_fn.first is not None and out.grad_fn.first[1].ok()
         (out.float() * w.float()).sum().backward()
         grads.append((a.grad.clone(), b.grad.clone(), out.detach()))
     assert torch.equal(grads[0][2], grads[1][2])
@@ -901,6 +905,81 @@ def test_gather_backward_through_the_first_occurrence_map(HF, Lb):
             for j, (v, ok) in enumerate(zip(row_g.tolist(), row_m.tolist())):
                 if ok:
                     assert first_pos[v] == j, (k, j, v)      # a VALID position is always the first reference to its source row
+
+
+def test_gather_backward_falls_back_when_a_valid_position_repeats_a_source(HF, Lb):
+    """VERDICT r5 #1c: the one-gather backward was hard-wired on a property of the REFERENCE's collate output.  It is checked
+    at run time now (functional.first_reference_map): an index that references a source row from two VALID positions fails
+    the check and gets the scatter-add backward, i.e. the sum of both gradients."""
+    dtype = torch.float32
+    na, nb, n = 6, 10, 16
+    src = torch.arange(16)
+    src[5] = 2                               # position 5 (valid) names source row 2 again; source row 5 is never referenced
+    src[12] = 9                              # ... and a txt row twice as well
+    idx = torch.where(src < na, src, -(src - na) - 2).to(torch.int32).cuda()
+    valid = torch.ones(n, dtype=torch.int64, device="cuda")
+    a0, b0, w = rnd(na, 64, dtype=dtype, seed=1), rnd(nb, 64, dtype=dtype, seed=2), rnd(n, 64, dtype=dtype, seed=3)
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    out = HF.GatherRowsFn.apply(a, b, idx, 0, valid)
+    assert out.grad_fn.first is not None and not out.grad_fn.first[1].ok()
+    (out * w).sum().backward()
+    ar, br = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    both = torch.cat([ar, br], 0)
+    (both[src.cuda()] * w).sum().backward()
+    torch.testing.assert_close(a.grad, ar.grad)
+    torch.testing.assert_close(b.grad, br.grad)
+    assert float(a.grad[2].abs().sum()) > 0 and torch.equal(a.grad[2], (w[2] + w[5]))
+    assert float(a.grad[5].abs().sum()) == 0
+    # the same index with the repeats MASKED passes the check (and then drops what the masked positions were sent)
+    valid2 = valid.clone()
+    valid2[5] = 0
+    valid2[12] = 0
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    out = HF.GatherRowsFn.apply(a, b, idx, 0, valid2)
+    assert out.grad_fn.first[1].ok()
+    w2 = w.clone()
+    w2[5] = 0
+    w2[12] = 0
+    (out * w2).sum().backward()
+    ar.grad = br.grad = None
+    (torch.cat([ar, br], 0)[src.cuda()] * w2).sum().backward()
+    torch.testing.assert_close(a.grad, ar.grad)
+    torch.testing.assert_close(b.grad, br.grad)
+    # without a mask nothing is assumed
+    out = HF.GatherRowsFn.apply(a0.clone().requires_grad_(True), b0.clone().requires_grad_(True), idx, 0, None)
+    assert out.grad_fn.first is None
+
+
+def test_model_with_a_caller_built_gather_index_gets_the_reference_gradients():
+    """The same at model level (tiny golden model, fp32): a batch whose f_gather_index names one frame row from two valid
+    positions.  torch.gather's backward (the reference, model/encoder.py:271-279) adds both gradients; so does the HIP path."""
+    import hero_amd
+    from oracle import hero_oracle as O
+    from tests.util import GOLDEN, load_tiny, rel_err, to_dev
+    from hero_amd.utils.misc import set_dropout
+    hero_amd.set_compute_dtype(torch.float32)
+    batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_train.npz"))
+    gi, am = batch["f_gather_index"].clone(), batch["f_attn_masks"]
+    row = int((am.sum(1) >= 3).nonzero()[0])
+    assert int(am[row, 1]) == 1 and int(am[row, 0]) == 1
+    gi[row, 1] = gi[row, 0]                                   # valid position 1 re-reads position 0's source row
+    batch = dict(batch, f_gather_index=gi)
+    model, P, cfg = load_tiny("cuda")
+    model.train()
+    set_dropout(model, 0.0)
+    HF_ = hero_amd.functional
+    HF_.set_grad_sink(None)
+    losses = model(to_dev(batch, "cuda"), task="tvr", compute_loss=True)
+    sum(l.sum() for l in losses).backward()
+    Pq = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in P.items()}
+    ref = O.vsm_losses(batch, Pq, cfg)
+    sum(ref).backward()
+    for got, want in zip(losses, ref):
+        assert rel_err(got, want) < 1e-3
+    grads = dict(model.named_parameters())
+    for name in ("v_encoder.f_encoder.img_embeddings.img_linear.weight", "v_encoder.f_encoder.embeddings.word_embeddings.weight",
+                 "v_encoder.f_encoder.img_embeddings.position_embeddings.weight"):
+        assert rel_err(grads[name].grad, Pq[name].grad) < 1e-3, name
 
 
 def test_attention_dropout_adjoint(HF, Lb):

@@ -113,50 +113,6 @@ def test_one_launch_weight_refresh_equals_per_tensor_casts():
         HF.clear_weight_cache()
 
 
-def test_adamw_writes_the_straight_compute_copies():
-    """Round 5 (opt-in, `AdamW.write_copies`): the fused AdamW kernel writes the cached straight (bf16, row-concatenated) compute copy of every parameter it
-    updates (HeroTensorDesc.shadow) - the same rounding of the same fp32 values as hero_copy_multi - and
-    refresh_weight_cache(straight_done=True) then only has the transposed copies left; a parameter the step skips keeps its copy;
-    fp32 packed copies (bias vectors) are shadows too."""
-    import hero_amd
-    from hero_amd import functional as HF, optim
-    hero_amd.set_compute_dtype(torch.bfloat16)
-    HF.clear_weight_cache()
-    torch.manual_seed(0)
-    ws = [torch.nn.Parameter(torch.randn(n, 96, device="cuda")) for n in (64, 130, 40)]
-    bs = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (64, 130, 40)]
-    lone = torch.nn.Parameter(torch.randn(33, 96, device="cuda"))
-    idle = torch.nn.Parameter(torch.randn(16, 96, device="cuda"))
-    try:
-        W, Wt, B = HF.packed(ws, torch.bfloat16), HF.packed_t(ws, torch.bfloat16), HF.packed(bs, torch.float32)
-        Lc, Ic = HF.packed((lone,), torch.bfloat16), HF.packed((idle,), torch.bfloat16)
-        idle_before = Ic.clone()
-        opt = optim.AdamW([{"params": ws + bs + [lone, idle], "weight_decay": 0.01}], lr=1e-2)
-        assert opt.write_copies is False                 # measured neutral-to-negative on MI355X: off by default (optim/adamw.py)
-        opt.write_copies = True
-        for p in ws + bs + [lone]:
-            p.grad = torch.randn_like(p)
-        for _ in range(2):
-            opt.step()                                  # `idle` has no gradient: skipped
-            assert opt.last_shadowed == frozenset(id(p) for p in ws + bs + [lone])
-            Wt_before = Wt.clone()
-            ref = torch.cat([p.detach() for p in ws], 0)
-            # straight copies are current straight out of the optimiser kernel, the transposed one is not yet
-            assert torch.equal(W, ref.to(torch.bfloat16)) and torch.equal(Lc, lone.detach().to(torch.bfloat16))
-            assert torch.equal(B, torch.cat([p.detach() for p in bs])) and torch.equal(Ic, idle_before)
-            assert torch.equal(Wt, Wt_before) and not torch.equal(Wt, ref.t().contiguous().to(torch.bfloat16))
-            HF.refresh_weight_cache(straight_done=True)
-            assert torch.equal(Wt, ref.t().contiguous().to(torch.bfloat16))
-            assert HF.packed(ws, torch.bfloat16) is W and HF.packed_t(ws, torch.bfloat16) is Wt      # cache hits
-        opt.write_copies = False                        # the old path: nothing shadowed, the refresh copies everything
-        opt.step()
-        assert opt.last_shadowed == frozenset() and not torch.equal(W, torch.cat([p.detach() for p in ws], 0).to(torch.bfloat16))
-        HF.refresh_weight_cache(straight_done=opt.write_copies)
-        assert torch.equal(W, torch.cat([p.detach() for p in ws], 0).to(torch.bfloat16))
-    finally:
-        HF.clear_weight_cache()
-
-
 def test_checkpoint_restore_after_steps_matches_uninterrupted_run():
     """optimiser.load_state_dict replaces the moment tensors; the AdamW descriptor tables must not
     keep pointing at the old ones.  save -> 2 more optimiser steps -> restore -> the same 2 steps == the first time."""

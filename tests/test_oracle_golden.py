@@ -94,6 +94,14 @@ def _task_batches(batch):
     return mlm, mfm, fom
 
 
+def _vsm_batch(batch):
+    """The several-queries-per-video VSM batch of case_pretrain.npz (data/vsm.py:105-145 keys)."""
+    vsm = {k: v for k, v in batch.items() if not k.startswith("vsm.") and k not in ("f_v_masks", "c_v_masks")}
+    for k in ("query_input_ids", "query_pos_ids", "query_attn_masks", "targets", "q_vidx"):
+        vsm[k] = batch["vsm." + k]
+    return vsm
+
+
 def _leaf_params(P0):
     return {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pad")) for k, v in P0.items()}
 
@@ -137,3 +145,19 @@ def test_pretrain_heads_match_reference(tiny, golden_dir):
     torch.testing.assert_close(loss.detach(), outs["fom.loss"], **TOL)
     loss.backward()
     _check_grads(P, outs, "fom")
+
+
+def test_vsm_with_several_queries_per_video_matches_reference(tiny, golden_dir):
+    """Round 6: configs[3]'s VSM batches carry query_per_video queries for every video (data/vsm.py:21,105-145), which takes
+    the reference through the CROSS branch of get_pred_from_mod_query and the [row, q_vidx] selection
+    (model/pretrain.py:93-99, 188-201) and through the per > 1 ranking loss.  The reference's three weighted losses and
+    five gradients on a 3-video x 2-query batch (one ignored start target) pin the oracle's restatement of it."""
+    P0, cfg = tiny
+    batch, outs = O.load_npz_case(os.path.join(golden_dir, "case_pretrain.npz"))
+    vsm = _vsm_batch(batch)
+    assert vsm["query_input_ids"].shape[0] == 2 * vsm["c_v_feats"].shape[0]
+    P = _leaf_params(P0)
+    losses = O.vsm_losses(vsm, P, cfg)
+    torch.testing.assert_close(torch.stack([l.reshape(()) for l in losses]).detach(), outs["vsm.losses"], **TOL)
+    sum(losses).backward()
+    _check_grads(P, outs, "vsm")

@@ -205,12 +205,15 @@ class DeviceCollate:
         self._in = {k: self._in_flat[o:o + n] for k, (o, n) in self._in_off.items()}
 
     @classmethod
-    def for_batch(cls, batch, device, **kw):
-        """Buffers sized for a (host) batch of video_collate."""
+    def for_batch(cls, batch, device, entry_capacity=None, **kw):
+        """Buffers sized for a (host) batch of video_collate.  entry_capacity: at least that much room for the frame lists."""
         T, max_vl = batch["f_v_feats"].shape[:2]
         B, NF = batch["c_attn_masks"].shape
+        cap = max(int(batch["lengths"]["sub_frm"].shape[0]), T * max_vl) if "lengths" in batch else None
+        if entry_capacity:
+            cap = max(cap or 0, int(entry_capacity))
         return cls(T, max_vl, batch["f_sub_input_ids"].shape[1], B, NF, device, out_size=batch["f_attn_masks"].shape[1],
-                   entry_capacity=max(int(batch["lengths"]["sub_frm"].shape[0]), T * max_vl) if "lengths" in batch else None, **kw)
+                   entry_capacity=cap, **kw)
 
     @property
     def frame_map(self):

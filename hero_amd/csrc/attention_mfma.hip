@@ -64,6 +64,21 @@ __device__ __forceinline__ void store_headT(bf16_t* __restrict__ dst, int ld, in
 // wave-uniform coordinates of a (sequence, head) pair; all of a wave's pairs are resolved at the kernel start (scalar loads
 // issued together - resolved later, behind wave-uniform branches, the sequence bounds became vector loads with a wait each)
 struct PairCoord { int s, h, row0, L; bool on; };
+
+// Where head h's Q / K / V (and ctx / dctx) columns live.  Product layout: the fused projection's rows [M, 3 * D] (Q | K | V,
+// head h at columns h * 64) and [M, D].  -DHERO_ATTN_LAB_HEADMAJOR (tools/lab/attn_layout_ab.py, round 6): per-head PANELS
+// [3][H][M][64] / [H][M][64] with M = S * L rows (unpacked launches only) - the layout VERDICT r5 #2 asked to price before
+// the QKV GEMM epilogue and the dgrad / wgrad loaders are taught to write / read it.
+struct HeadLay { int ld, ldc; size_t q, k, v, c; };
+__device__ __forceinline__ HeadLay head_lay(const HeroAttn& a, int h) {
+  [[maybe_unused]] const int D = a.H * 64;
+#ifdef HERO_ATTN_LAB_HEADMAJOR
+  const size_t P = (size_t)a.S * a.L * 64;
+  return {64, 64, (size_t)h * P, (size_t)(a.H + h) * P, (size_t)(2 * a.H + h) * P, (size_t)h * P};
+#else
+  return {3 * D, D, (size_t)h * 64, (size_t)D + h * 64, (size_t)2 * D + h * 64, (size_t)h * 64};
+#endif
+}
 template <int CLS>
 __device__ __forceinline__ PairCoord pair_coord(const HeroAttn& a, int pair) {
   const int P = a.S * a.H;
@@ -122,16 +137,19 @@ struct FwdIn {
 template <int NB, bool M4>
 __device__ __forceinline__ void fwd_issue(const HeroAttn& a, const PairCoord& pcd, FwdIn<NB>& in, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
-  const int s = pcd.s, h = pcd.h, D = a.H * 64, ld = 3 * D;
+  const int s = pcd.s, h = pcd.h;
+  const HeadLay hl = head_lay(a, h);
+  const int ld = hl.ld;
   const int row0 = pcd.row0, L = pcd.L;
   in.s = s; in.h = h; in.row0 = row0; in.L = L; in.on = pcd.on;
   // A pair this launch does not own (the other length class of a packed batch, or past the end) is not computed; its loads
   // stay in the instruction stream - a wave-uniform branch around them made the compiler wait vmcnt(0) behind every issue,
   // i.e. no prefetch at all - but all go to row 0 of the tensor (one cache line per operand), selected without a branch.
   const int Lc = pcd.on ? L : 1;
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)(pcd.on ? row0 : 0) * ld + h * 64;
-  const bf16_t* kp = qp + D;
-  const bf16_t* vp = qp + 2 * D;
+  const bf16_t* rowp = static_cast<const bf16_t*>(a.qkv) + (size_t)(pcd.on ? row0 : 0) * ld;
+  const bf16_t* qp = rowp + hl.q;
+  const bf16_t* kp = rowp + hl.k;
+  const bf16_t* vp = rowp + hl.v;
   const int c = (lane & 7) * 8;
 #pragma unroll
   for (int it = 0; it < 4 * NB; ++it) {
@@ -164,7 +182,7 @@ __device__ __forceinline__ void fwd_stage(const FwdIn<NB>& in, bf16_t* Vs, int l
 template <int NB>
 __device__ __forceinline__ void fwd_compute(const HeroAttn& a, const FwdIn<NB>& in, const bf16_t* Vs, const DropCtx& drop, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
-  const int s = in.s, h = in.h, row0 = in.row0, L = in.L, D = a.H * 64;
+  const int s = in.s, h = in.h, row0 = in.row0, L = in.L;
   const int Lm = a.L, Lp = (Lm + 3) & ~3;
   // ---- S^T[jt][it] = K Q^T
   f32x16_t sc[NB][NB];
@@ -258,7 +276,10 @@ __device__ __forceinline__ void fwd_compute(const HeroAttn& a, const FwdIn<NB>& 
           cx[dt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][jt][ks], pack8(&p[jt][8 * ks]), cx[dt][it], 0, 0, 0);
     }
   }
-  store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * D + h * 64, D, L, cx, lane);
+  {
+    const HeadLay hl = head_lay(a, h);
+    store_headT<NB>(static_cast<bf16_t*>(a.ctx) + (size_t)row0 * hl.ldc + hl.c, hl.ldc, L, cx, lane);
+  }
 }
 
 template <int NB, int WPB, int CLS, int PPW, bool M4>       // second bound: waves per SIMD the two-pair kernel must fit (<= 168 registers)
@@ -314,14 +335,17 @@ struct BwdIn {
 template <int NB, bool RC, bool M4>
 __device__ __forceinline__ void bwd_issue(const HeroAttn& a, const PairCoord& pcd, BwdIn<NB>& in, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
-  const int s = pcd.s, h = pcd.h, D = a.H * 64, ld = 3 * D;
+  const int s = pcd.s, h = pcd.h;
+  const HeadLay hl = head_lay(a, h);
+  const int ld = hl.ld, D = hl.ldc;
   const int row0 = pcd.row0, L = pcd.L;
   in.s = s; in.h = h; in.row0 = row0; in.L = L; in.on = pcd.on;
   const int Lc = pcd.on ? L : 1;                         // not owned: every load goes to row 0 (see fwd_issue)
-  const bf16_t* qp = static_cast<const bf16_t*>(a.qkv) + (size_t)(pcd.on ? row0 : 0) * ld + h * 64;
-  const bf16_t* kp = qp + D;
-  const bf16_t* vp = qp + 2 * D;
-  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)(pcd.on ? row0 : 0) * D + h * 64;
+  const bf16_t* rowp = static_cast<const bf16_t*>(a.qkv) + (size_t)(pcd.on ? row0 : 0) * ld;
+  const bf16_t* qp = rowp + hl.q;
+  const bf16_t* kp = rowp + hl.k;
+  const bf16_t* vp = rowp + hl.v;
+  const bf16_t* op = static_cast<const bf16_t*>(a.dctx) + (size_t)(pcd.on ? row0 : 0) * D + hl.c;
   const int c = (lane & 7) * 8;
 #pragma unroll
   for (int it = 0; it < 4 * NB; ++it) {
@@ -362,7 +386,9 @@ __device__ __forceinline__ void bwd_compute(const HeroAttn& a, const BwdIn<NB>& 
   constexpr int R = 32 * NB;
   constexpr int PS = R + 8;                              // [query][key] bf16 row stride (elements)
   const int half = lane >> 5, l31 = lane & 31;
-  const int s = in.s, h = in.h, row0 = in.row0, L = in.L, D = a.H * 64, ld = 3 * D;
+  const int s = in.s, h = in.h, row0 = in.row0, L = in.L;
+  const HeadLay hl = head_lay(a, h);
+  const int ld = hl.ld;
   const int Lm = a.L, Lp = (Lm + 3) & ~3;
   bf16_t* Qs = Ks + R * RS;
   bf16_t* Os = Qs + R * RS;
@@ -419,7 +445,8 @@ __device__ __forceinline__ void bwd_compute(const HeroAttn& a, const BwdIn<NB>& 
         kf[dt][jt][ks] = tr_frag(tr_addr(Ks, RS * 2, r0, dt, lane), tr_addr(Ks, RS * 2, r0 + 8, dt, lane));
       }
 
-  bf16_t* dq = static_cast<bf16_t*>(a.dqkv) + (size_t)row0 * ld + h * 64;
+  bf16_t* dqrow = static_cast<bf16_t*>(a.dqkv) + (size_t)row0 * ld;
+  bf16_t* dq = dqrow + hl.q;
   f32x16_t gq[2][NB];
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
@@ -538,8 +565,8 @@ __device__ __forceinline__ void bwd_compute(const HeroAttn& a, const BwdIn<NB>& 
         }
       }
     }
-  store_headT<NB>(dq + D, ld, L, gk, lane);
-  store_headT<NB>(dq + 2 * D, ld, L, gv, lane);
+  store_headT<NB>(dqrow + hl.k, ld, L, gk, lane);
+  store_headT<NB>(dqrow + hl.v, ld, L, gv, lane);
 }
 
 template <int NB, int WPB, bool RC, int CLS, int PPW, bool M4>       // second bound: at least two waves per SIMD (<= 256 registers) for the multi-pair kernels

@@ -227,8 +227,8 @@ class BertEncoder(nn.Module):
         self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None):
-        if (self.pack_ragged and BertEncoder.allow_packing and attention_mask is not None and hidden_states.is_cuda
-                and attention_mask.dim() == 2 and attention_mask.dtype != torch.float32):
+        if (self.pack_ragged and BertEncoder.allow_packing and BertEncoder.packing_mode != "none" and attention_mask is not None
+                and hidden_states.is_cuda and attention_mask.dim() == 2 and attention_mask.dtype != torch.float32):
             return (self.forward_multi([hidden_states], [attention_mask])[0],)
         x = HF.cast(hidden_states, HF.compute_dtype())
         S, Lq, _ = x.shape
@@ -281,6 +281,100 @@ class BertEncoder(nn.Module):
         BertEncoder._PLANS[key] = (plan, mask_list)          # keep the masks alive: ids stay unique
         return plan
 
+    # ---- a pack plan with FIXED buffer sizes, refreshed from the host (round 6) ---------------------------------------
+    # The plan above is derived from the masks on the host per batch and fixes the packed row COUNT: a captured hipGraph
+    # would replay the capture batch's plan.  A static plan has a row CAPACITY instead (a bucket, >= the valid rows of
+    # every batch it serves): the rows behind the valid ones are zero rows grouped into pad "sequences" of <= PAD_CHUNK
+    # rows, so every row of every per-layer buffer is written by some kernel (a row no kernel writes would hand
+    # uninitialised memory to the weight-gradient reduction), their upstream gradient is exactly zero, and nothing
+    # downstream reads them.  All of it - gather / inverse / per-group maps / sequence offsets - lives in ONE int32
+    # buffer whose contents a feeder (hero_amd.loader.StaticBatchFeeder(packed_rows=...)) rebuilds on the host from the
+    # next batch's masks and copies in; shapes, sequence count and the attention length class never change.
+    PAD_CHUNK = 32
+    _STATIC_PLANS = {}      # addresses of the mask tensors of the groups -> (plan tuple, masks kept alive)
+    packing_mode = "all"    # "all" | "static" (registered static plans only: batches whose buffers are rewritten) | "none"
+
+    @staticmethod
+    def static_plan_layout(group_shapes, rows_cap, min_rows=0, lmax=None):
+        """Offsets (int32 elements) of the sections of a static plan's buffer.  group_shapes: ((S, L), ...) of the padded
+        groups; rows_cap: packed rows (valid + pad); min_rows: the smallest number of valid rows this plan will see (bounds the
+        number of pad sequences); lmax: attention length class (default: the longest group row, at most 64)."""
+        r4 = lambda n: (n + 3) & ~3            # noqa: E731
+        total = sum(S * L_ for S, L_ in group_shapes)
+        n_real = sum(S for S, _ in group_shapes)
+        n_pad = -(-max(rows_cap - min_rows, 0) // BertEncoder.PAD_CHUNK)
+        lay, off = {}, 0
+        for name, n in [("gather", rows_cap), ("inverse", total)] + [("back%d" % g, rows_cap) for g in range(len(group_shapes))] + \
+                [("off", n_real + n_pad + 1)]:
+            lay[name] = (off, n)
+            off += r4(n)
+        lay.update(size=off, total=total, n_real=n_real, n_pad=n_pad, n_seq=n_real + n_pad, rows_cap=rows_cap, min_rows=min_rows,
+                   groups=tuple(tuple(g) for g in group_shapes),
+                   lmax=lmax or min(64, max(max(L_ for _, L_ in group_shapes), BertEncoder.PAD_CHUNK)))
+        return lay
+
+    @staticmethod
+    def fill_static_plan(flat, lay, masks):
+        """Write the plan of one batch into `flat` (a numpy int32 array of lay['size'] elements: pinned host memory).
+        masks: one 0/1 array [S, L] per group, already padded to the layout's group shapes.  Same maps as `_pack_plan`
+        (valid positions in row-major order, groups back to back), + the pad rows.  Returns the number of valid rows."""
+        import numpy as np
+        cap, chunk = lay["rows_cap"], BertEncoder.PAD_CHUNK
+        valid_flat = np.concatenate([np.asarray(m).reshape(-1) != 0 for m in masks])
+        counts = np.concatenate([(np.asarray(m) != 0).sum(1).reshape(-1) for m in masks]).astype(np.int64)
+        if valid_flat.size != lay["total"] or counts.size != lay["n_real"]:
+            raise ValueError("static pack plan: masks of %d positions / %d rows, the plan was laid out for %d / %d" %
+                             (valid_flat.size, counts.size, lay["total"], lay["n_real"]))
+        valid = int(valid_flat.sum())
+        if not lay["min_rows"] <= valid <= cap:
+            raise ValueError("static pack plan: %d valid rows outside this bucket's [%d, %d]" % (valid, lay["min_rows"], cap))
+        if counts.size and int(counts.max()) > lay["lmax"]:
+            raise ValueError("static pack plan: a sequence of %d valid positions, the attention class is %d" % (int(counts.max()), lay["lmax"]))
+        sec = lambda name: flat[lay[name][0]:lay[name][0] + lay[name][1]]      # noqa: E731
+        gather = np.flatnonzero(valid_flat).astype(np.int32)
+        g = sec("gather")
+        g[:valid] = gather
+        g[valid:] = -1
+        inv = sec("inverse")
+        inv[:] = -1
+        inv[gather] = np.arange(valid, dtype=np.int32)
+        r0 = 0
+        for gi, (S, L_) in enumerate(lay["groups"]):
+            b = sec("back%d" % gi)
+            rel = gather.astype(np.int64) - r0
+            b[:valid] = np.where((rel >= 0) & (rel < S * L_), rel, -1).astype(np.int32)
+            b[valid:] = -1
+            r0 += S * L_
+        off = sec("off")
+        off[0] = 0
+        off[1:lay["n_real"] + 1] = np.cumsum(counts)
+        pad = cap - valid                                    # pad rows as sequences of <= chunk rows, the rest empty
+        steps = np.minimum(np.arange(1, lay["n_pad"] + 1, dtype=np.int64) * chunk, pad)
+        off[lay["n_real"] + 1:] = valid + steps
+        assert lay["n_pad"] * chunk >= pad and int(off[-1]) == cap
+        return valid
+
+    @staticmethod
+    def register_static_plan(masks, flat, lay):
+        """flat: the DEVICE int32 buffer (lay['size'] elements) a feeder refreshes; masks: the device mask tensors of the
+        groups, in forward_multi's order - the plan is found by their addresses (their contents / versions change per batch)."""
+        v = lambda name: flat[lay[name][0]:lay[name][0] + lay[name][1]]      # noqa: E731
+        inverse = v("inverse")
+        inv, r0 = [], 0
+        for S, L_ in lay["groups"]:
+            inv.append(inverse[r0:r0 + S * L_])
+            r0 += S * L_
+        plan = (v("gather"), inverse, inv, [v("back%d" % g) for g in range(len(lay["groups"]))], v("off"), lay["n_seq"], lay["lmax"])
+        BertEncoder._STATIC_PLANS[tuple(m.data_ptr() for m in masks)] = (plan, list(masks), lay)
+        return plan
+
+    @staticmethod
+    def _static_plan_for(mask_list, segs):
+        hit = BertEncoder._STATIC_PLANS.get(tuple(m.data_ptr() for m in mask_list))
+        if hit is None or hit[2]["groups"] != tuple(segs):
+            return None
+        return hit[0]
+
     def forward_multi(self, hidden_list, mask_list):
         """Run several independent sequence groups (tensors (S_i, L_i, D) + their (S_i, L_i) 0/1
         masks) through the SAME layer stack as one stacked row batch: GEMMs, LayerNorms and their
@@ -298,9 +392,14 @@ class BertEncoder(nn.Module):
         D = xs[0].shape[-1]
         x = HF.StackRowsFn.apply(*[t.reshape(-1, D) for t in xs]) if len(xs) > 1 else xs[0].reshape(-1, D)
         plan = None
-        if self.pack_ragged and BertEncoder.allow_packing and all(m is not None for m in mask_list) and x.is_cuda:
-            plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs],
-                                   max_len=L.lib().hero_attention_max_packed_len(L.BF16 if cd == torch.bfloat16 else L.F32))
+        mode = BertEncoder.packing_mode if BertEncoder.allow_packing else "none"
+        if self.pack_ragged and mode != "none" and all(m is not None for m in mask_list) and x.is_cuda:
+            max_len = L.lib().hero_attention_max_packed_len(L.BF16 if cd == torch.bfloat16 else L.F32)
+            plan = self._static_plan_for(mask_list, segs)
+            if plan is not None and plan[6] > max_len:
+                plan = None
+            if plan is None and mode == "all":
+                plan = self._pack_plan(mask_list, [s[0] * s[1] for s in segs], max_len=max_len)
         if plan is not None:
             gather, inverse, inv, back, off, n_seq, lmax = plan
             x = HF.PermuteRowsFn.apply(x.contiguous(), gather, inverse)

@@ -38,21 +38,31 @@ def qkv_groups(model):
     return groups
 
 
-class _padded_only:
-    """Switch the packed (ragged) formulation of BertEncoder off for the duration (no-op when `on` is false)."""
+class _packing:
+    """Restrict the packed (ragged) formulation of BertEncoder for the duration: "all" = no restriction, "static" = only
+    plans a feeder registered with fixed buffer sizes (BertEncoder.register_static_plan), "none" = padded formulation."""
 
-    def __init__(self, on):
-        self.on = bool(on)
+    def __init__(self, mode):
+        self.mode = mode
 
     def __enter__(self):
-        if self.on:
-            from .model.layers import BertEncoder
-            self.prev, BertEncoder.allow_packing = BertEncoder.allow_packing, False
+        from .model.layers import BertEncoder
+        self.prev, BertEncoder.packing_mode = BertEncoder.packing_mode, self.mode
 
     def __exit__(self, *exc):
-        if self.on:
-            from .model.layers import BertEncoder
-            BertEncoder.allow_packing = self.prev
+        from .model.layers import BertEncoder
+        BertEncoder.packing_mode = self.prev
+
+
+def _packing_mode_of(batch):
+    """A batch whose BUFFERS are rewritten between steps (hero_amd.loader.StaticBatchFeeder, DeviceCollate batches fed to a
+    captured step) must not run a pack plan derived from its masks on the host: the packed row COUNT would be the capture
+    batch's on every later batch.  It runs padded - or, when its feeder owns a static plan (fixed row capacity,
+    refreshed with every batch: `_static_plan`), packed through that plan.  Enforced for eager steps on such batches too, so
+    both modes compute the same thing."""
+    if not hasattr(batch, "get") or not batch.get("_static_buffers"):
+        return "all"
+    return "static" if batch.get("_static_plan") else "none"
 
 
 class TrainStep:
@@ -83,7 +93,8 @@ class TrainStep:
         if graph_collectives is None:
             graph_collectives = os.environ.get("HERO_DP_GRAPH", "0") not in ("", "0")
         self.use_graph = use_graph and (not D.collectives_active() or (graph_collectives and uniform_shapes))
-        self._graphs = {}             # task -> (plain graph, its loss, boundary graph, its loss, static batch)
+        self.counts = {"replayed": 0, "eager_in_graph_mode": 0, "captures": 0}
+        self._graphs = {}             # task, or (task, bucket) for a feeder's bucket batches -> (plain graph, its loss, boundary graph, its loss, static batch)
         self._window = []             # tasks of the micro-steps accumulated since the last optimiser step
         # compute copies of the weights are cached per optimiser step: anything else that rewrites parameters
         # (checkpoint restore, EMA swap) must invalidate them
@@ -108,12 +119,7 @@ class TrainStep:
         # replay (a capture freezes the site numbers it saw; counting on across steps made the two modes draw different
         # masks), the per-step seed word keeps the steps apart - graph replay and eager runs follow one trajectory
         HF.RNG.site = 0
-        # A batch whose BUFFERS are rewritten between steps (hero_amd.loader.StaticBatchFeeder, DeviceCollate batches fed to
-        # a captured step) must run the padded formulation: the packed one derives a row plan - and the packed row COUNT -
-        # from the masks on the host, a captured graph would replay the plan of the capture batch on every later batch
-        # (ADVICE r3).  Enforced here, for eager steps on such batches too, so both modes compute the same thing.
-        with _padded_only(batch.get("_static_buffers") if hasattr(batch, "get") else False), HF.weights_frozen(), \
-                D.uniform_shapes(self.uniform_shapes):
+        with _packing(_packing_mode_of(batch)), HF.weights_frozen(), D.uniform_shapes(self.uniform_shapes):
             out = self.model(batch, task=task or self.task, compute_loss=True)
             # 'tvr' / 'vsm': (loss_st_ed, loss_neg_ctx, loss_neg_q) summed (train_vcmr.py:216-226, pretrain.py:283-290);
             # 'mlm' / 'mfm-nce' / 'fom': one loss tensor
@@ -144,12 +150,17 @@ class TrainStep:
         return lr
 
     # ---- eager -------------------------------------------------------------------------------------
-    def micro_step(self, batch, task=None):
+    def micro_step(self, batch, task=None, eager=False):
         """One forward+backward; optimiser step on accumulation boundaries. Returns the loss
         tensor (device-resident, not synchronised).  task: this micro-step's task (multi-task
-        pre-training, pretrain.py:274-350); default: the task given at construction."""
+        pre-training, pretrain.py:274-350); default: the task given at construction.
+        eager: in graph mode, run THIS micro-step with eager launches (a batch no captured graph fits - e.g. one that none
+        of a BucketedBatchFeeder's buckets held); it shares the accumulation window and the device-side optimiser state
+        with the replayed ones."""
         task = task or self.task
         if self.use_graph:
+            if eager:
+                return self._eager_step_in_graph_mode(batch, task)
             return self._graph_step(batch, task)
         accum = self.opts.gradient_accumulation_steps
         boundary = (self.micro + 1) % accum == 0
@@ -186,6 +197,31 @@ class TrainStep:
         self.micro += 2 * accum
         self._record(batch, task)
 
+    @staticmethod
+    def _key(batch, task):
+        """Graphs are per task and - for the static batches of a hero_amd.loader.BucketedBatchFeeder - per bucket shape."""
+        bucket = batch.get("_bucket") if hasattr(batch, "get") else None
+        return task if bucket is None else (task, bucket)
+
+    def _eager_step_in_graph_mode(self, batch, task):
+        """One micro-step with eager launches that keeps the graph mode's books: the accumulation window, the device-side
+        optimiser step / learning rate the captured boundary graphs read."""
+        accum = self.opts.gradient_accumulation_steps
+        boundary = (self.micro + 1) % accum == 0
+        self.counts["eager_in_graph_mode"] += 1
+        self._window.append(task)
+        if len(set(self._window)) > 1:
+            raise RuntimeError("graph mode: one accumulation window mixes tasks %s" % sorted(set(self._window)))
+        if boundary:
+            self._window = []
+        self.arena.set_sync(boundary)
+        loss = self._fwd_bwd(batch, task)
+        self.micro += 1
+        if boundary:
+            self._lr_t.fill_(self._set_lr())
+            self._optimise(device_state=True)
+        return loss
+
     def _record(self, batch, task):
         """Capture the two graphs of `task` (every lazy state exists already).  Also used to RE-capture a task whose
         graphs are older than the newest compute copy of a weight: the captured weight-copy refresh covers the copies
@@ -202,18 +238,20 @@ class TrainStep:
         with torch.cuda.graph(gb, pool=ga.pool(), **mode):
             loss_b = self._fwd_bwd(batch, task)
             self._optimise(device_state=True)
-        self._graphs[task] = (ga, loss_a, gb, loss_b, batch)
+        key = self._key(batch, task)
+        self.counts["captures"] += 1
+        self._graphs[key] = (ga, loss_a, gb, loss_b, batch)
         self._graph_gen = getattr(self, "_graph_gen", {})
-        self._graph_gen[task] = HF.weight_cache_generation()
+        self._graph_gen[key] = HF.weight_cache_generation()
         self._active_of = getattr(self, "_active_of", {})
-        self._active_of[task] = list(getattr(self.optimizer, "last_active", []))     # for prebuild() before a re-capture
+        self._active_of[key] = list(getattr(self.optimizer, "last_active", []))     # for prebuild() before a re-capture
 
     def prepare(self, batch, task=None):
         """One-time setup outside any timed region: in graph mode the eager warm-up micro-steps and the
         capture of the two graphs of `task` on `batch`'s buffers (a no-op otherwise / when already done)."""
         task = task or self.task
         if self.use_graph:
-            if task not in self._graphs:
+            if self._key(batch, task) not in self._graphs:
                 self._capture(batch, task)
         elif task not in getattr(self, "_prepared", set()):
             for _ in range(self.opts.gradient_accumulation_steps):   # one full cycle: every lazy state exists
@@ -226,15 +264,31 @@ class TrainStep:
         skips.  Hence (a) only the captured batch OBJECT is accepted - new data of identical structure (same masks,
         lengths, frame maps) may be copied into its tensors, anything else needs a new capture; (b) all micro-steps
         of one accumulation window must be of the same task."""
-        if task not in self._graphs:
-            self._capture(batch, task)
+        key = self._key(batch, task)
+        if key not in self._graphs:
+            if not any((k if isinstance(k, str) else k[0]) == task for k in self._graphs):
+                self._capture(batch, task)           # first graphs of this task: full eager warm-up (every lazy state), then capture
+            else:
+                # another BUCKET of a task that is already captured (BucketedBatchFeeder): every lazy state that does not
+                # depend on the batch exists.  Its FIRST batch runs eagerly on the new static batch (memoised tensors,
+                # weight-gradient plans and workspaces come into being - no extra optimiser steps, no batch seen twice);
+                # the bucket's two graphs are captured the next time it comes up at the START of an accumulation window
+                # (a capture runs the host side of a whole step: it must not land between a window's micro-steps), and
+                # until then its batches keep running eagerly.
+                seen = self.__dict__.setdefault("_seen_eager", set())
+                if key in seen and self.micro % self.opts.gradient_accumulation_steps == 0:
+                    torch.cuda.synchronize()
+                    self._record(batch, task)
+                else:
+                    seen.add(key)
+                    return self._eager_step_in_graph_mode(batch, task)
         accum = self.opts.gradient_accumulation_steps
-        if self.micro % accum == 0 and self._graph_gen[task] != HF.weight_cache_generation():
+        if self.micro % accum == 0 and self._graph_gen[key] != HF.weight_cache_generation():
             torch.cuda.synchronize()                 # window start: re-capture against the current set of weight copies
             if hasattr(self.optimizer, "prebuild"):  # its descriptor table holds the copies' addresses: build the new one eagerly
-                self.optimizer.prebuild(self._active_of.get(task, []))
-            self._record(self._graphs[task][4], task)
-        ga, loss_a, gb, loss_b, static_batch = self._graphs[task]
+                self.optimizer.prebuild(self._active_of.get(key, []))
+            self._record(self._graphs[key][4], task)
+        ga, loss_a, gb, loss_b, static_batch = self._graphs[key]
         if batch is not static_batch:
             raise RuntimeError("graph mode replays the captured batch buffers (and the index / mask tensors derived "
                                "from them at capture): copy new data of the SAME structure into them, or run eagerly")
@@ -247,6 +301,7 @@ class TrainStep:
         if boundary:
             self._window = []
         self.micro += 1
+        self.counts["replayed"] += 1
         if boundary:
             self._lr_t.fill_(self._set_lr())        # stream-ordered scalar fill (no pinned-buffer race)
             gb.replay()

@@ -858,6 +858,12 @@ def memo(tag, tensors, fn, extra=(), spec=None):
     hit = _MEMO.get(key)
     if hit is not None:
         return hit[0]
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # A miss while a hipGraph is being captured is computed INSIDE that graph and not remembered: a remembered entry would
+        # live in the graph's private pool and be found - not recomputed - by the next capture (TrainStep records a plain
+        # and a boundary graph back to back), which would then depend on the other graph's last replay (round 6: found by
+        # the bucketed feeder, whose commits move the version counters between a bucket's first eager step and its capture).
+        return fn()
     if len(_MEMO) > 512:
         _MEMO.clear()
     out = fn()
@@ -927,6 +933,9 @@ def refresh_memo(sources=None, skip_outputs=()):
     ptrs = None if sources is None else {t.data_ptr() for t in sources}
     batch, later = [], []
     skip_ids = {id(t) for t in skip_outputs}                  # entries the caller refreshes itself (host-computed orders)
+    if sources is not None:                                    # what this call keeps current (the caller may restamp_memo them)
+        src_ptrs = set(ptrs)
+        _LAST_REFRESHED[:] = [k for k, e in _MEMO.items() if any(t.data_ptr() in src_ptrs for t in e[1])]
     entries = [e for e in _MEMO.values() if id(e[0]) not in skip_ids]
     # entries a hero_derive_multi launch computes (functions of ONE raw int64 batch tensor) first, then the entries with a
     # builder of their own, which may be derived from those (segment_order sorts int32 row indices that are themselves
@@ -953,6 +962,30 @@ def refresh_memo(sources=None, skip_outputs=()):
                 raise RuntimeError("refresh_memo: a derived tensor changed shape %s -> %s; the batch structure is "
                                    "different, not just its contents" % (tuple(out.shape), tuple(new.shape)))
             out.copy_(new)
+
+
+_LAST_REFRESHED = []
+
+
+def last_refreshed_keys():
+    """Keys of the memo entries derived DIRECTLY from the `sources` of the last refresh_memo(sources=...) call."""
+    return list(_LAST_REFRESHED)
+
+
+def restamp_memo(keys):
+    """Re-key memo entries to the CURRENT version counters of their sources and return the new keys.  For a caller that has
+    just refreshed exactly these entries in place by other means - a replayed hipGraph of refresh_memo - and then moved the
+    sources' version counters (hero_amd.loader.StaticBatchFeeder.commit): the entries ARE current, and a later lookup - an
+    eager step, or the capture of another step graph - must find them instead of rebuilding beside them."""
+    out = []
+    for k in keys:
+        e = _MEMO.pop(k, None)
+        if e is None:
+            continue
+        nk = (k[0], k[1]) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in e[1])
+        _MEMO[nk] = e
+        out.append(nk)
+    return out
 
 
 def as_mask_add(mask, S, Lq):

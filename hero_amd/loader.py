@@ -195,6 +195,7 @@ class StaticBatchFeeder:
         self.stage_order = [{}, {}]
         self._order_ok = [False, False]
         self._versioned = None
+        self._memo_keys = []
         self._want_graph = capture_commit
         self.plan = None
         if packed_rows:
@@ -281,6 +282,9 @@ class StaticBatchFeeder:
             self._graph[s].replay()
             # a replay does not move the version counters the eager-mode caches (functional.memo) key on
             torch._C._increment_version(self._versioned)       # takes an ITERABLE of tensors (a bare tensor is iterated row by row)
+            # ... but the entries the commit graph has just refreshed in place ARE current: re-key them, so that whoever looks
+            # them up next (an eager step, the capture of another bucket's step graphs) finds them instead of rebuilding
+            self._memo_keys = HF.restamp_memo(self._memo_keys)
         else:
             self._commit_body(s)
         self._consumed[s].record(cur)
@@ -307,6 +311,7 @@ class StaticBatchFeeder:
             with torch.cuda.graph(g):
                 self._commit_body(s)
             self._graph[s] = g
+        self._memo_keys = HF.last_refreshed_keys()           # the memo entries the commit graphs keep current
         self._versioned = [t for t in self.static.values() if torch.is_tensor(t)] + [t for t in self.dc.frame_map]
         torch.cuda.synchronize(self.device)
 

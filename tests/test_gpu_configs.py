@@ -224,7 +224,7 @@ def test_hero_base_bf16_pretraining_heads_at_bench_size_vs_oracle(task):
         b["c_v_feats"] = b["c_v_feats"].clone()                  # forward_mfm mutates it (model/model.py:244-247)
         got = model(b, task="mfm-nce", compute_loss=True)
         assert got.shape == ref.shape == (n_masked,)
-        report["loss.l2"], report["loss.mean"] = l2_err(got, ref), abs(float(got.mean()) - float(ref.mean())) / float(ref.mean())
+        report["loss.l2"], report["loss.mean"] = l2_err(got, ref), abs(float(got.detach().mean()) - float(ref.detach().mean())) / float(ref.detach().mean())
         ref.mean().backward()
         got.mean().backward()
     elif task == "fom":
@@ -252,8 +252,13 @@ def test_hero_base_bf16_pretraining_heads_at_bench_size_vs_oracle(task):
         report["grad." + n] = l2_err(params[n].grad, Pq[n].grad)
     print(task, json.dumps(report, indent=1))
     HF.clear_weight_cache()
-    assert all(v < 2e-2 for k, v in report.items() if k.startswith("loss.") or k.startswith("logits.")), report
-    assert all(v < 0.06 for k, v in report.items() if k.startswith("grad.")), report
+    # measured on MI355X (round 6): loss values 5e-5 ... 2.6e-3 (FOM logits 1.1e-2 L2); gradients, relative L2: MFM-NCE 3.3 - 4.1 %
+    # (its logits are inner products with the RAW 4352-wide feature targets: |logit| ~ 60, one bf16 ulp of a logit is 0.25),
+    # FOM / VSM 0.9 - 1.9 % and 3.9 % for frame_transform.net.1.weight (as on the D2 batch)
+    assert all(v < 5e-3 for k, v in report.items() if k.startswith("loss.")), report
+    assert all(v < 2e-2 for k, v in report.items() if k.startswith("logits.")), report
+    gate = 0.055 if task == "mfm-nce" else 0.03
+    assert all(v < (0.05 if "frame_transform" in k else gate) for k, v in report.items() if k.startswith("grad.")), report
 
 
 def test_bf16_error_growth_per_layer():

@@ -22,7 +22,7 @@ for _ in range(NSET):
     sets.append(dict(qkv=qkv, dctx=dctx, ctx=torch.empty(S * Lq, D, device="cuda", dtype=dt), dq=torch.empty_like(qkv)))
 madd = torch.zeros(S, Lq, device="cuda")
 madd[:, -2:] = -10000.0
-drop = HF.RNG.make(0.1, True, "cuda")
+drop = HF.RNG.make(0.1, True, torch.device("cuda", 0))
 for s_ in sets:
     _, s_["saved"] = HF.k_attn_fwd(s_["qkv"], madd, S, Lq, H, drop=drop, out=s_["ctx"])
 

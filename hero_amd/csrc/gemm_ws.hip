@@ -1180,6 +1180,12 @@ extern "C" int hero_wgrad_batch_plan(const HeroWgradProblem* probs, int n, int K
       int Sx = c / p;
       while (Sx > 1 && ksteps / Sx < 4) --Sx;
       if (Sx > 8) Sx = 8;
+      // Round 6 (profiles/r06_wgrad_ceiling.txt: the 92 tiles of the 4352-wide projection gradient, 30 k-steps, ran 59 us in two
+      // slices where their main loops take 18): a sliced tile pays ~16 us of ordered fp32 atomics PER SLICE - slice s waits for
+      // slice s - 1 to drain - where a whole tile pays ~8 us of plain read-add-write, and a k-step is ~1.2 us.  Slices only
+      // where they save more k-steps than that: short reductions (the 1920-row and 480-row groups) keep whole tiles.
+      auto cost_us = [&](int sl) { return (double)((ksteps + sl - 1) / sl) * 1.17 + (sl == 1 ? 8.0 : 9.0 + 16.0 * sl); };
+      while (Sx > 1 && cost_us(Sx - 1) <= cost_us(Sx)) --Sx;
       const int L = c - Sx * p;
       // workgroups left over (c / p not whole) take the remainders - where the reduction is long enough that a piece's own
       // epilogue (a tile of atomics, ~4 k-steps' worth) does not eat the gain: ksteps >= 128, pieces of >= 4 steps

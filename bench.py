@@ -364,6 +364,42 @@ def feed_ragged_run(device, rank, steps, warmup, n_batches=8, n_buckets=3):
                      "per bucket, packed cross-modal layers (static pack plan rebuilt on the host per batch)" % n_batches}
 
 
+def live_pmc(timeout_s=200):
+    """the HBM-traffic and MFMA-busy counters on the line used to be READ from a committed profile.  When
+    rocprofv3 is on PATH, take them in THIS run: three short passes of this very command (2 eager micro-steps each, `--pmc`
+    alone with --kernel-trace, separate passes as MI355X_MICROARCH.md prescribes) as subprocesses after the timed region,
+    summarised by tools/profile_summary.py into a scratch directory.  Returns (traffic json, mfma json, note) or None - any
+    failure (no rocprofv3, a refused counter, a timeout) leaves the line with the stamped committed profile."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_summary as PS
+    d = tempfile.mkdtemp(prefix="hero_pmc_")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+           "--no-graph", "--no-box-probe", "--profile-steps", "0"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for tag, ctr in (("f", ["FETCH_SIZE"]), ("w", ["WRITE_SIZE"]), ("m", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"])):
+            r = subprocess.run(["rocprofv3", "--pmc"] + ctr + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, tag), "-o", tag, "--"] + cmd,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            PS.pmc(os.path.join(d, "f"), os.path.join(d, "w"), os.path.join(d, "traffic.json"))
+            PS.mfma(os.path.join(d, "m"), os.path.join(d, "mfma.json"))
+        return (os.path.join(d, "traffic.json"), os.path.join(d, "mfma.json"),
+                "measured in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes of this command (2 eager "
+                "micro-steps each, subprocesses after the timed region, %.0f s; FETCH x2 gfx950 correction)" % (time.perf_counter() - t0))
+    except Exception:                                    # noqa: BLE001 - the committed profile stays the source
+        return None
+
+
 def _forget_previous_models():
     """Between the workloads of one process: the package caches compute copies of the weights per parameter object (and refreshes
     ALL of them after every optimiser step) and memoises tensors derived from batches - a later workload must not pay for, or
@@ -457,6 +493,10 @@ def main():
                     help="N = 1: skip the short D2r / D3 / feed runs attached to the D2 line as `secondary`")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the ~0.5 s MFMA / HBM probes of the box")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not take the three short rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE, MFMA-busy) "
+                         "after the timed region; `roofline.traffic / hbm_gbps / mfma_busy` then come from the committed profile "
+                         "(stamped with the kernel-source hash).  Implied by --no-secondary (what the profiling scripts pass).")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
     ap.add_argument("--workload", default="D2", choices=["D2", "D2r", "D3", "D4"],
                     help="D2 (default, the headline line): BASELINE configs[1]/[2]; secondary lines: D2r = ragged TVR "
@@ -626,11 +666,12 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS if slot >= 4 else 157.3      # slots 0-3 are the fp32 parity-mode kernels
             traffic, tsrc = None, None
+            live = live_pmc() if (world == 1 and not dist_on and not args.no_live_pmc and not args.no_secondary and not args.feed) else None
             want = {4: "gemm_glds_kernel<unsigned short", 5: "gemm_kernel<unsigned short, 0, 1",
                     7: "gemm_glds_tr_kernel", 8: "gemm_ws_kernel<3, 3, false", 9: "gemm_ws",
                     10: "gemm_ws_kernel<2, 3, false"}.get(slot)
             try:                                   # HBM bytes per launch from the committed PMC passes, stamped with the
-                pj = os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)     # kernel sources they were taken with
+                pj = live[0] if live else os.path.join(ROOT, "profiles", PROFILE_TRAFFIC)     # kernel sources they were taken with
                 pm = json.load(open(pj))
                 meta = pm.pop("_meta", {})
                 hits = [v for k, v in pm.items() if want and want in k and (slot != 9 or ", false," not in k)]
@@ -640,9 +681,10 @@ def main():
                     same = meta.get("csrc_sha16") == csrc_sha16()
                     tot = sum(h["launches"] for h in hits)
                     traffic = sum(h["hbm_bytes_per_launch_corrected"] * h["launches"] for h in hits) / tot
-                    tsrc = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH x2 gfx950 correction), "
-                            "taken with kernel sources %s = %s" % (PROFILE_TRAFFIC, meta.get("csrc_sha16"),
-                                                                  "the sources of this build" if same else "NOT this build's sources (stale)"))
+                    tsrc = live[2] if live else (
+                        "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH x2 gfx950 correction), "
+                        "taken with kernel sources %s = %s" % (PROFILE_TRAFFIC, meta.get("csrc_sha16"),
+                                                              "the sources of this build" if same else "NOT this build's sources (stale)"))
             except Exception:
                 pass
             # north_star: "rocprof-reported HBM GB/s and MFMA utilisation against chip peak" - counters cannot be read
@@ -653,7 +695,7 @@ def main():
             if traffic:
                 hbm_gbps = traffic / (ms * 1e-3 / n) / 1e9
             try:
-                mm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_MFMA)))
+                mm = json.load(open(live[1] if live else os.path.join(ROOT, "profiles", PROFILE_MFMA)))
                 mm.pop("_meta", None)
                 mh = [v for k, v in mm.items() if want and want in k and (slot != 9 or ", false," not in k)]
                 if mh:
@@ -672,7 +714,8 @@ def main():
                     "frac_of_peak_measured": round(ach / box["mfma_bf16_tflops"], 4) if box and box.get("mfma_bf16_tflops") and slot >= 4 else None,
                     "hbm_peak_measured": box.get("hbm_copy_gbps") if box else None,
                     "clock_ghz": box.get("mfma_clock_ghz") if box else None,
-                    "counters_source": "profiles/%s + profiles/%s (rocprofv3 --pmc passes of this command)" % (PROFILE_TRAFFIC, PROFILE_MFMA)}
+                    "counters_source": live[2] if live else
+                    "profiles/%s + profiles/%s (rocprofv3 --pmc passes of this command, committed)" % (PROFILE_TRAFFIC, PROFILE_MFMA)}
     elif world > 1:
         for _ in range(args.profile_steps):
             trainer.micro_step(batch)

@@ -338,7 +338,8 @@ def _run_batch(Lb, probs, n, rows):
 def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     """hero_wgrad_batch: the weight gradients of ALL layers of an encoder over the same rows in one launch - whole
     192 x 192 tiles in full rounds (plain fp32 read-add-write), the last partial round cut into k-slices with ordered
-    atomics.  (1920, 3) = the Temporal Transformer (576 tiles: 2 rounds + 64 tiles x 4 slices), (12000, 6) = the
+    atomics.  (1920, 3) = the Temporal Transformer (576 tiles: 2 rounds + 64 tail tiles - round 6: WHOLE tiles, a 30-step
+    reduction does not pay for ordered atomics, profiles/r06_wgrad_ceiling.txt; rounds 3-5: 4 slices), (12000, 6) = the
     cross-modal stack of the benched step (1152 tiles: 4 rounds + 128 tiles x 2 slices), 1000 rows: a reduction tail;
     (8192, 1) / (8200, 5): 192 tail tiles, >= 128 k-steps = ONE BertLayer (what config 5's queue cap flushes at a time) - round 4's balanced
     tail: a 3/4 slice per tile on 192 workgroups, the quarters packed three to a workgroup on the other 64.
@@ -357,7 +358,9 @@ def test_wgrad_batch_whole_tiles(HF, Lb, rows, layers):
     first_db = [d.clone() for d in dbs]
     assert plan[6] == layers * 192
     if (rows, layers) in ((1920, 3), (1000, 6)):
-        assert plan[7] > 1                      # the tail round is sliced
+        assert plan[7] == 1                     # short reductions: the tail round keeps whole tiles (no atomics at all)
+    if (rows, layers) == (12000, 6):
+        assert plan[7] == 2                     # the long one is sliced: 128 tail tiles x 2 slices, ordered atomics
     if layers in (1, 5):                        # 192 tail tiles (24 per XCD on 32 workgroups): big slices + packed remainders
         assert plan[2] > layers * 192 // 256 + 1
     first = [o.clone() for o in outs]

@@ -1,10 +1,11 @@
-// GEMM lab 5: wave-specialised workgroup.  C[M,N] = A[M,K] B[N,K]^T, bf16 in / bf16 out, fp32 accumulate.
-//   8 waves per workgroup, ONE workgroup per CU: waves 0-3 compute (2 x 2, each TM x TN MFMA 32x32 tiles,
-//   fragments double-buffered in registers, one slice of 16 k ahead), waves 4-7 only issue the
-//   direct-to-LDS loads into an NS-stage ring (counted vmcnt, raw s_barrier, one barrier per 64-k step).
-//   Tile (64 TM) x (64 TN) x 64; 192 x 192 fills 252 of 256 CUs for M = 12000, N = 768 k.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTM=3 -DTN=3 -DNS=3 [-DNO_MFMA] [-DNO_LOADS] [-DNO_EPI] gemm_ws.hip -o ws_x
-// Run:   ./ws_x [M N K]...      (no args: the HERO step's M = 12000 shapes)
+// GEMM lab 12 (round 6): the one geometry DESIGN 4a-4d had not tried - a wave-specialised 256 x 192 tile at THREE
+// waves per SIMD: 8 compute waves (4 x 2, each 64 x 96 = 2 x 3 MFMA 32x32 tiles: 96 accumulators, <= 168 registers) + 4 loader
+// waves that only issue direct-to-LDS loads, 32-k stages (28 KB) in a five-deep ring (140 KB).  Against the product's 192 x 192
+// tile it moves 12.5 % fewer DMA bytes per FLOP (56 KB per 64 k for 256 x 192 against 48 KB for 192 x 192) at the price of 25 % more
+// fragment-read bytes per FLOP (every A byte is read by 2 waves, every B byte by 4) and a barrier every 12 MFMAs instead of 36.
+// C[M,N] = A[M,K] B[N,K]^T, bf16 in / bf16 out, fp32 accumulate; one tile per workgroup (no persistence: the loops are the question).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DNO_EPI] [-DNO_MFMA] [-DNO_LOADS] gemm_ws12.hip -o lab12_x
+// Run:   ./lab12_x [M N K]...   (no args: the N = 3072 / K = 3072 shapes of the step); compare with tools/lab/gemm_ws.hip (-DTM=3 -DTN=3)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -14,32 +15,27 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-#ifndef TM
-#define TM 3
-#endif
-#ifndef TN
-#define TN 3
-#endif
 #ifndef NS
-#define NS 3
+#define NS 5
 #endif
 #ifndef GROUP
 #define GROUP 8
 #endif
-constexpr int BM = 64 * TM, BN = 64 * TN;
-constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-constexpr int PA = BM / 32, PB = BN / 32, PW = PA + PB;   // 1-KiB pieces per loader wave per stage
-constexpr int LDC = BN + 4;                               // fp32 staging row (floats)
-constexpr int EPI_BYTES = BM * LDC * 4;
+constexpr int BM = 256, BN = 192, BK = 32;
+constexpr int ROWB = BK * 2;                                  // 64-byte LDS rows: four 16-byte chunks, swizzled by (row >> 2) & 3
+constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+constexpr int PA = A_BYTES / 1024 / 4, PB = B_BYTES / 1024 / 4, PW = PA + PB;   // 1-KiB pieces per loader wave per stage: 4 + 3
+constexpr int TMW = 2, TNW = 3;                               // MFMA tiles per compute wave
+constexpr int LDC = BN + 4;
+constexpr int EPI_BYTES = (BM / 2) * LDC * 4;                 // the epilogue stages half a tile at a time
 constexpr int LDS_BYTES = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+static_assert(LDS_BYTES <= 160 * 1024 && (NS - 2) * PW < 64, "LDS / vmcnt budget");
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
@@ -52,39 +48,37 @@ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t*
   const int m0 = pid_m * BM, n0 = pid_n * BN;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nk = K / 64;
+  const int nk = K / BK;
 
-  f32x16_t acc[TM][TN];
+  f32x16_t acc[TMW][TNW];
   int arow0 = 0, brow0 = 0;
 
-  if (wave >= 4) {
-    // ------------------------------------------------------------------ loader waves
-    const int w = wave - 4;
-    // buffer descriptors of the tile's row panels (raw, no stride); per-lane byte offsets are fixed for the
-    // whole K loop, the k advance is the scalar offset, M0 carries the LDS destination: no VALU per load
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader waves (one per SIMD)
+    const int w = wave - 8;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * K), 0, 0x7fffffff, 0x00020000);
     unsigned goa[PA], gob[PB];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int r = (w * PA + i) * 8 + (lane >> 3);
-      goa[i] = (unsigned)(min(m0 + r, M - 1) - m0) * (unsigned)K * 2u + (((lane & 7) ^ swz(r)) << 4);
+    for (int i = 0; i < PA; ++i) {                                  // a 1-KiB piece = 16 LDS rows x 4 chunks; lane -> (row, position)
+      const int r = (w * PA + i) * 16 + (lane >> 2);
+      goa[i] = (unsigned)(min(m0 + r, M - 1) - m0) * (unsigned)K * 2u + (((lane & 3) ^ swz(r)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int r = (w * PB + i) * 8 + (lane >> 3);
-      gob[i] = (unsigned)(min(n0 + r, N - 1) - n0) * (unsigned)K * 2u + (((lane & 7) ^ swz(r)) << 4);
+      const int r = (w * PB + i) * 16 + (lane >> 2);
+      gob[i] = (unsigned)(min(n0 + r, N - 1) - n0) * (unsigned)K * 2u + (((lane & 3) ^ swz(r)) << 4);
     }
-    unsigned fill = 0;                                              // byte offset of the stage being filled
+    unsigned fill = 0;
     auto issue = [&](int t) {
 #ifndef NO_LOADS
       char* buf = smem + fill;
 #pragma unroll
       for (int i = 0; i < PA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(buf + (w * PA + i) * 1024), 16, goa[i], t * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(buf + (w * PA + i) * 1024), 16, goa[i], t * ROWB, 0, 0);
 #pragma unroll
       for (int i = 0; i < PB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(buf + A_BYTES + (w * PB + i) * 1024), 16, gob[i], t * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(buf + A_BYTES + (w * PB + i) * 1024), 16, gob[i], t * ROWB, 0, 0);
 #endif
       fill += STAGE;
       if (fill == NS * STAGE) fill = 0;
@@ -102,40 +96,40 @@ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t*
       __builtin_amdgcn_s_barrier();                                 // B(t)
     }
   } else {
-    // ------------------------------------------------------------------ compute waves
+    // ------------------------------------------------------------------ compute waves (two per SIMD)
     const int wm = wave >> 1, wn = wave & 1;
-    arow0 = wm * TM * 32; brow0 = wn * TN * 32;
+    arow0 = wm * TMW * 32; brow0 = wn * TNW * 32;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int r = lane & 31, kg = lane >> 5;
-    unsigned ao[TM], bo[TN];                                        // LDS byte offsets inside a stage, slice 0
+    unsigned ao[TMW], bo[TNW];                                      // LDS byte offsets inside a stage, k-slice 0 (chunk kg); slice 1 = ^ 32
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { const int ra = arow0 + i * 32 + r; ao[i] = ra * 128 + ((kg ^ swz(ra)) << 4); }
+    for (int i = 0; i < TMW; ++i) { const int rr = arow0 + i * 32 + r; ao[i] = rr * ROWB + ((kg ^ swz(rr)) << 4); }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { const int rb = brow0 + j * 32 + r; bo[j] = A_BYTES + rb * 128 + ((kg ^ swz(rb)) << 4); }
-    bf16x8_t a0[TM], b0[TN], a1[TM], b1[TN];
-    auto ldf = [&](bf16x8_t (&a)[TM], bf16x8_t (&b)[TN], const char* st, int ks) {
+    for (int j = 0; j < TNW; ++j) { const int rr = brow0 + j * 32 + r; bo[j] = A_BYTES + rr * ROWB + ((kg ^ swz(rr)) << 4); }
+    bf16x8_t a0[TMW], b0[TNW], a1[TMW], b1[TNW];
+    auto ldf = [&](bf16x8_t (&a)[TMW], bf16x8_t (&b)[TNW], const char* st, int ks) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(st + (ao[i] ^ (ks << 5)));
+      for (int i = 0; i < TMW; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(st + (ao[i] ^ (ks << 5)));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(st + (bo[j] ^ (ks << 5)));
+      for (int j = 0; j < TNW; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(st + (bo[j] ^ (ks << 5)));
     };
-    auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
+    auto mma = [&](const bf16x8_t (&a)[TMW], const bf16x8_t (&b)[TNW]) {
 #ifndef NO_MFMA
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TNW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // swapped: lane = m row
 #else
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) { acc[i][j][0] += (float)a[i][0] * (float)b[j][0]; }
+        for (int j = 0; j < TNW; ++j) { acc[i][j][0] += (float)a[i][0] * (float)b[j][0]; }
 #endif
     };
     __builtin_amdgcn_s_setprio(3);
@@ -151,14 +145,6 @@ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t*
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      ldf(a0, b0, cur, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      ldf(a1, b1, cur, 3);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                 // B(t): done reading `cur`, stage t+1 landed
       __builtin_amdgcn_sched_barrier(0);
@@ -171,28 +157,30 @@ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t*
   }
 
 #ifndef NO_EPI
-  // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> bf16 rows, 16 B per lane
+  // ---- epilogue (plain, two halves of 128 rows): accumulators -> LDS (fp32, padded rows) -> bf16 rows, 16 B per lane
   float* lc = reinterpret_cast<float*>(smem);
-  __syncthreads();
-  if (wave < 4) {
-    const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wave < 8 && (wave >> 2) == half) {
+      const int r = lane & 31, kg = lane >> 5;
+      const int lrow0 = ((wave >> 1) & 1) * TMW * 32;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          *reinterpret_cast<f32x4_t*>(lc + (arow0 + i * 32 + r) * LDC + brow0 + j * 32 + 8 * g + 4 * kg) = v;
-        }
-  }
-  __syncthreads();
-  {
-    constexpr int C8 = BN / 8, RPI = 512 / C8;
-    const int c8 = threadIdx.x % C8, r0 = threadIdx.x / C8;
-    if (r0 < RPI) {
-      for (int row = r0; row < BM; row += RPI) {
-        const int gm = m0 + row;
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<f32x4_t*>(lc + (lrow0 + i * 32 + r) * LDC + brow0 + j * 32 + 8 * g + 4 * kg) = v;
+          }
+    }
+    __syncthreads();
+    {
+      constexpr int C8 = BN / 8, RPI = 768 / C8;
+      const int c8 = threadIdx.x % C8, r0 = threadIdx.x / C8;
+      for (int row = r0; row < BM / 2; row += RPI) {
+        const int gm = m0 + half * (BM / 2) + row;
         const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(lc + row * LDC + c8 * 8);
         const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(lc + row * LDC + c8 * 8 + 4);
         uint4 o;
@@ -205,12 +193,12 @@ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t*
     }
   }
 #else
-  if (wave < 4) {                                                   // every accumulator stays live (a single-element test lets the compiler delete MFMAs)
+  if (wave < 8) {                                                   // every accumulator stays live (a single-element test lets the compiler delete MFMAs)
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
     if (sum == 123.456f) C[0] = 1;
@@ -247,14 +235,16 @@ static void run(int M, int N, int K, bool verify) {
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int grid = ((M + BM - 1) / BM) * (N / BN);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 60; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, A, B, C, M, N, K);   // past the clock ramp
+  // past the clock ramp (tools/lab/warm_probe.py: the first ~70 ms after idle run up to 20 % slower)
+  for (int i = 0; i < 60; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(768), lds, 0, A, B, C, M, N, K);
   hipEventRecord(e0);
   const int n = 40;
-  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, 0, A, B, C, M, N, K);
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(768), lds, 0, A, B, C, M, N, K);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / n;
   double worst = -1; long bad = 0;
+#ifndef NO_EPI
   if (verify) {
     hipLaunchKernelGGL(ref_k, dim3((N + 255) / 256, M), dim3(256), 0, 0, A, B, R, M, N, K);
     std::vector<uint16_t> hc((size_t)M * N), hr((size_t)M * N);
@@ -267,8 +257,9 @@ static void run(int M, int N, int K, bool verify) {
       if (d > worst) worst = d;
     }
   }
-  printf("ws TM=%d TN=%d NS=%d lds=%dK grid=%d M=%d N=%d K=%d  %.1f us  %.1f TF/s  maxabs %.3g bad %ld (%s)\n", TM, TN, NS, lds >> 10, grid, M, N, K, us,
-         2.0 * M * N * K / us / 1e6, worst, bad, hipGetErrorString(hipGetLastError()));
+#endif
+  printf("ws12 256x192x32 NS=%d lds=%dK grid=%d (%.2f rounds) M=%d N=%d K=%d  %.1f us  %.1f TF/s  maxabs %.3g bad %ld (%s)\n", NS, lds >> 10, grid,
+         grid / 256.0, M, N, K, us, 2.0 * M * N * K / us / 1e6, worst, bad, hipGetErrorString(hipGetLastError()));
   hipFree(A); hipFree(B); hipFree(C); hipFree(R);
 }
 
@@ -277,7 +268,7 @@ int main(int argc, char** argv) {
     for (int i = 1; i + 2 < argc; i += 3) run(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]), true);
     return 0;
   }
-  const int shapes[][3] = {{12000, 768, 768}, {12000, 2304, 768}, {12000, 3072, 768}, {12000, 768, 3072}, {12000, 768, 2304}, {12096, 3072, 3072}};
+  const int shapes[][3] = {{12000, 3072, 768}, {12000, 768, 3072}, {12000, 2304, 768}, {12032, 3072, 3072}};
   for (auto& s : shapes) run(s[0], s[1], s[2], true);
   return 0;
 }

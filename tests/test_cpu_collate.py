@@ -159,3 +159,117 @@ def test_host_segment_order_is_a_stable_sort_with_dropped_rows_last():
         want = torch.sort(key, stable=True).indices.to(torch.int32)
         got = torch.from_numpy(HF.host_segment_order(ids.numpy(), skip))
         assert torch.equal(got, want)
+
+
+# ---- round 6: bucket padding and the static pack plan (host halves of hero_amd.loader.BucketedBatchFeeder) -------------------
+def _ragged_host_batches(n, seed0=40):
+    from hero_amd import synth
+    out = []
+    for s in range(n):
+        gen = torch.Generator().manual_seed(seed0 + s)
+        ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))     # noqa: E731
+        subs, n_frames = [], []
+        for v in range(2):
+            nf, cur, f0 = ri(18, 32), [], 0
+            for s_ in range(ri(4, 8)):
+                fr = list(range(f0, min(f0 + ri(0, 4), nf)))
+                f0 += len(fr)
+                cur.append((fr, ri(2, 9)))
+            subs.append(cur)
+            n_frames.append(nf)
+        b = synth.video_batch(subs, n_frames, 96, 128, gen)                 # the tiny golden model: vfeat 96, vocabulary 160
+        b.update(synth.query_batch(2, [ri(4, 12), ri(4, 12)], 128, gen))
+        b["targets"] = torch.tensor([[1, 3], [2, ri(3, 9)]])
+        b["q_vidx"] = torch.arange(2)
+        out.append(b)
+    return out
+
+
+def test_bucket_padding_is_a_legal_reference_batch():
+    """loader.pad_batch / derive_buckets / BucketPadder on the host: a padded batch has the bucket's shapes, the original
+    contents, the reference's padding conventions (data/data.py:406-471: id 1, mask 0, zero features, gather index of the
+    new max_vl), lengths DeviceCollate can consume - and the ORACLE gives the original batch's ranking losses on it (padded
+    positions are masked out of every score) and a start / end loss within the convolution's edge effect."""
+    import pickle
+    from hero_amd.collate import vcmr_collate
+    from hero_amd.loader import BucketPadder, BucketedBatchFeeder, batch_dims, bucket_of, pad_batch, pad_to_bucket
+    from oracle import hero_oracle as O
+    P, cfgj, _, _ = O.load_npz_model(os.path.join(GOLDEN, "tiny_model.npz"))
+    cfg = O.cfg_from_json(cfgj)
+    host = _ragged_host_batches(6)
+    dims = [batch_dims(h) for h in host]
+    buckets = BucketedBatchFeeder.derive_buckets(dims, n_buckets=3, row_quantum=16)
+    assert 2 <= len(buckets) <= 3 and all(b["rows"] % 16 == 0 for b in buckets)
+    assert all(a["rows"] < b["rows"] and b["min_rows"] == a["rows"] + 1 for a, b in zip(buckets, buckets[1:]))
+    pickle.loads(pickle.dumps(BucketPadder(buckets, vcmr_collate)))                 # a DataLoader worker can carry it
+    for h, d in zip(host, dims):
+        i = bucket_of(d, buckets)
+        assert i >= 0 and buckets[i]["min_rows"] <= d["rows"] <= buckets[i]["rows"]
+        assert i == 0 or d["rows"] > buckets[i - 1]["rows"]                           # the smallest capacity that holds it
+        j, p = pad_to_bucket(h, buckets)
+        assert j == i == p["_bucket"]
+        b = buckets[i]
+        pd = batch_dims(p)
+        assert all(pd[k] == b[k] for k in ("T", "max_vl", "max_sl", "Lf", "NF", "Lq")) and pd["rows"] == d["rows"]
+        T, Lf = d["T"], d["Lf"]
+        assert torch.equal(p["f_sub_input_ids"][:T, :d["max_sl"]], h["f_sub_input_ids"]) and int((p["f_sub_input_ids"][T:] != 1).sum()) == 0
+        assert torch.equal(p["f_attn_masks"][:T, :Lf], h["f_attn_masks"]) and int(p["f_attn_masks"][T:].sum()) == 0
+        assert torch.equal(p["c_v_feats"][:, :d["NF"]], h["c_v_feats"]) and float(p["c_v_feats"][:, d["NF"]:].abs().sum()) == 0
+        assert torch.equal(p["query_attn_masks"][:, :d["Lq"]], h["query_attn_masks"])
+        # the gather index is get_gather_index (data/data.py:504-512) for the bucket's max_vl: frames first, then the tokens
+        for r in range(T):
+            n_valid = int(h["f_attn_masks"][r].sum())
+            src_h = h["f_gather_index"][r][h["f_attn_masks"][r] == 1]
+            src_p = p["f_gather_index"][r][p["f_attn_masks"][r] == 1]
+            assert n_valid == len(src_p)
+            assert torch.equal(torch.where(src_h >= d["max_vl"], src_h - d["max_vl"] + b["max_vl"], src_h), src_p)
+        assert len(p["lengths"]["sub_nfrm"]) == b["T"] and int(p["lengths"]["vid_sub_off"][-1]) == b["T"]
+        assert p["num_subs"][-1] == h["num_subs"][-1] + b["T"] - T
+        want = [float(x) for x in O.vsm_losses(h, P, cfg)]
+        got = [float(x) for x in O.vsm_losses(p, P, cfg)]
+        np.testing.assert_allclose(got[1:], want[1:], rtol=1e-5, atol=1e-6)
+        assert abs(got[0] - want[0]) < 0.05 * abs(want[0])
+    assert pad_batch(p, buckets[p["_bucket"]]) is p                                   # already at the bucket's shape: untouched
+    big = dict(host[0])
+    big["query_input_ids"] = torch.nn.functional.pad(host[0]["query_input_ids"], (0, 40), value=1)
+    big["query_attn_masks"] = torch.nn.functional.pad(host[0]["query_attn_masks"], (0, 40))
+    assert pad_to_bucket(big, buckets)[0] == -1                                       # no bucket holds it: the caller runs it eagerly
+
+
+def test_static_pack_plan_is_the_dynamic_plan_plus_pad_rows():
+    """BertEncoder.fill_static_plan (numpy, what StaticBatchFeeder.prefetch runs per batch) builds the maps BertEncoder._pack_plan
+    derives from device masks - valid positions in row-major order, the groups back to back - and appends the pad rows as pad
+    sequences of <= 32 rows up to the plan's fixed capacity; the sequence count, every buffer size and the attention length class
+    depend on the LAYOUT only."""
+    from hero_amd.model.layers import BertEncoder as BE
+    host = _ragged_host_batches(4)
+    from hero_amd.loader import BucketedBatchFeeder, batch_dims, pad_to_bucket
+    buckets = BucketedBatchFeeder.derive_buckets([batch_dims(h) for h in host], n_buckets=1, row_quantum=16)
+    lay = None
+    for h in host:
+        _, p = pad_to_bucket(h, buckets)
+        masks = [p["f_attn_masks"], p["query_attn_masks"]]
+        groups = tuple(tuple(m.shape) for m in masks)
+        new = BE.static_plan_layout(groups, buckets[0]["rows"], buckets[0]["min_rows"])
+        assert lay is None or {k: v for k, v in new.items()} == lay                   # one layout for every batch of the bucket
+        lay = new
+        flat = np.full(lay["size"], 12345, dtype=np.int32)
+        valid = BE.fill_static_plan(flat, lay, [m.numpy() for m in masks])
+        assert valid == batch_dims(h)["rows"]
+        sec = lambda n: flat[lay[n][0]:lay[n][0] + lay[n][1]]      # noqa: E731
+        fl = torch.cat([(m != 0).reshape(-1) for m in masks])
+        gather = torch.nonzero(fl).reshape(-1).to(torch.int32).numpy()
+        assert np.array_equal(sec("gather")[:valid], gather) and (sec("gather")[valid:] == -1).all()
+        inv = np.full(fl.numel(), -1, np.int32)
+        inv[gather] = np.arange(valid)
+        assert np.array_equal(sec("inverse"), inv)
+        n0 = masks[0].numel()
+        assert np.array_equal(sec("back0")[:valid], np.where(gather < n0, gather, -1)) and (sec("back0")[valid:] == -1).all()
+        assert np.array_equal(sec("back1")[:valid], np.where(gather >= n0, gather - n0, -1))
+        off = sec("off")
+        counts = torch.cat([(m != 0).sum(1) for m in masks]).numpy()
+        assert off[0] == 0 and np.array_equal(np.diff(off[:lay["n_real"] + 1]), counts)
+        pad = np.diff(off[lay["n_real"]:])
+        assert (pad >= 0).all() and pad.max() <= BE.PAD_CHUNK and int(off[-1]) == lay["rows_cap"] and len(off) == lay["n_seq"] + 1
+    with pytest.raises(ValueError):
+        BE.fill_static_plan(flat, dict(lay, rows_cap=valid - 1), [m.numpy() for m in masks])      # more valid rows than the capacity

@@ -63,8 +63,10 @@ def bwd(s_):
 
 
 tag = os.environ.get("HERO_HIP_LIB", "product").split("/")[-1]
-fh, bh = t([fwd(sets[0])] * NSET), t([bwd(sets[0])] * NSET)
-fc, bc = t([fwd(s_) for s_ in sets]), t([bwd(s_) for s_ in sets])
 mb_f, mb_b = 71.0, 142.0                                  # 3 M D e + M D e forward; + dctx, dqkv backward
-print("%-26s HOT  fwd %5.1f us  bwd %5.1f us  (%.2f / %.2f TB/s)   COLD fwd %5.1f us  bwd %5.1f us  (%.2f / %.2f TB/s)" %
-      (tag, fh, bh, mb_f / fh, mb_b / bh, fc, bc, mb_f / fc, mb_b / bc), flush=True)
+for ppw in ([0] if "ppw" not in sys.argv else [1, 2, 3, 0]):      # `ppw`: also sweep the pairs-per-wave hook, HOT and COLD
+    L.check(L.lib().hero_attention_force_ppw(ppw))
+    fh, bh = t([fwd(sets[0])] * NSET), t([bwd(sets[0])] * NSET)
+    fc, bc = t([fwd(s_) for s_ in sets]), t([bwd(s_) for s_ in sets])
+    print("%-22s ppw %-4s HOT  fwd %5.1f us  bwd %5.1f us  (%.2f / %.2f TB/s)   COLD fwd %5.1f us  bwd %5.1f us  (%.2f / %.2f TB/s)" %
+          (tag, ppw or "auto", fh, bh, mb_f / fh, mb_b / bh, fc, bc, mb_f / fc, mb_b / bc), flush=True)

@@ -2,7 +2,7 @@
 # kernel stats of the secondary workloads, the bench lines.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out; mkdir -p $OUT
-TAG=${1:-r05}
+TAG=${1:-r06}
 bash tools/profile_run.sh $TAG > $OUT/${TAG}_run.log 2>&1
 export TMPDIR=/tmp
 R=$PWD

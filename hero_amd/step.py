@@ -272,16 +272,23 @@ class TrainStep:
                 # another BUCKET of a task that is already captured (BucketedBatchFeeder): every lazy state that does not
                 # depend on the batch exists.  Its FIRST batch runs eagerly on the new static batch (memoised tensors,
                 # weight-gradient plans and workspaces come into being - no extra optimiser steps, no batch seen twice);
-                # the bucket's two graphs are captured the next time it comes up at the START of an accumulation window
-                # (a capture runs the host side of a whole step: it must not land between a window's micro-steps), and
-                # until then its batches keep running eagerly.
+                # the bucket's two graphs are captured at the first window boundary it meets - right behind an eager step
+                # of its own that closed a window, or the next time it comes up at the start of one (a capture runs the
+                # host side of a whole step: it must not land between a window's micro-steps) - i.e. by its second batch.
                 seen = self.__dict__.setdefault("_seen_eager", set())
                 if key in seen and self.micro % self.opts.gradient_accumulation_steps == 0:
                     torch.cuda.synchronize()
                     self._record(batch, task)
                 else:
                     seen.add(key)
-                    return self._eager_step_in_graph_mode(batch, task)
+                    loss = self._eager_step_in_graph_mode(batch, task)
+                    if self.micro % self.opts.gradient_accumulation_steps == 0:
+                        # that eager step closed its window: this IS a window start, and the bucket's lazy state exists now -
+                        # capture at once (a bucket whose batches always fall on the boundary micro-step - eight batches
+                        # cycling under accumulation 2 keep their parity - would otherwise never meet a window start)
+                        torch.cuda.synchronize()
+                        self._record(batch, task)
+                    return loss
         accum = self.opts.gradient_accumulation_steps
         if self.micro % accum == 0 and self._graph_gen[key] != HF.weight_cache_generation():
             torch.cuda.synchronize()                 # window start: re-capture against the current set of weight copies

@@ -13,4 +13,5 @@ if __name__ == "__main__":
     import hero_amd
     hero_amd.set_compute_dtype(torch.bfloat16)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    print(json.dumps(bench.feed_ragged_run("cuda:0", 0, steps=steps, warmup=6)))
+    nb = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    print(json.dumps(bench.feed_ragged_run("cuda:0", 0, steps=steps, warmup=6, n_buckets=nb)))

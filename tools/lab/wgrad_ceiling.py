@@ -28,6 +28,15 @@ LAUNCHES = [
 ]
 
 
+# `d4probe` (argv): how the D4 queue should group its flushes - per-tile cost of several groupings at 397056 rows
+D4_PROBE = [
+    ("D4 probe: 1 layer (192 tiles, balanced tail)", 397056, LAYER, 1),
+    ("D4 probe: 1 layer + FFN2 of the next (256 tiles = one whole round)", 397056, LAYER + [(768, 3072)], 1),
+    ("D4 probe: 2 layers (384 tiles)", 397056, LAYER * 2, 1),
+    ("D4 probe: 4 layers (768 tiles = three whole rounds)", 397056, LAYER * 4, 1),
+]
+
+
 def timer(torch):
     def t(fn, reps):
         end = time.time() + 0.25
@@ -74,7 +83,7 @@ def measure(kind, out):
         L.check(L.lib().hero_probe_hbm(a.data_ptr(), b.data_ptr(), n, C.byref(cp), C.byref(rd), st))
         res["box"] = {"mfma_tflops": tf.value, "ghz": ghz.value, "hbm_copy_gbps": cp.value, "hbm_read_gbps": rd.value}
         del a, b
-    for name, rows, shapes, per_step in LAUNCHES:
+    for name, rows, shapes, per_step in (D4_PROBE if kind == "d4probe" else LAUNCHES):
         dys = [torch.randn(rows, n_, device="cuda", dtype=dt) for n_, _ in shapes]
         xs = [torch.randn(rows, k_, device="cuda", dtype=dt) for _, k_ in shapes]
         outs = [torch.zeros(n_, k_, device="cuda") for n_, k_ in shapes]
@@ -88,6 +97,8 @@ def measure(kind, out):
         fn = lambda: L.check(L.lib().hero_wgrad_batch(pr, n, rows, L.BF16, plan.data_ptr(), words, L.stream()))     # noqa: E731
         reps = 6 if rows <= 20000 else 2
         row = {"us": t(fn, reps), "tiles": int(buf[6]), "rounds": int(buf[2]), "slices": int(buf[7])}
+        row["us_per_tile_round"] = row["us"] / (row["tiles"] / 256.0)
+        row["tflops"] = sum(2.0 * rows * a_ * b_ for a_, b_ in shapes) / row["us"] / 1e6
         if kind == "product":
             def lib():
                 for dy, x in zip(dys, xs):

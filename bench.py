@@ -378,6 +378,8 @@ def live_pmc(timeout_s=200):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import profile_summary as PS
     d = tempfile.mkdtemp(prefix="hero_pmc_")
+    import atexit
+    atexit.register(shutil.rmtree, d, True)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
            "--no-graph", "--no-box-probe", "--profile-steps", "0"]
     env = dict(os.environ, TMPDIR="/tmp")

@@ -892,6 +892,9 @@ def reset_caches():
     del _WQ[:]
     del _CQ[:]
     set_grad_sink(None)
+    from .model.layers import BertEncoder          # pack plans keep their mask tensors (whole batches) alive
+    BertEncoder._PLANS.clear()
+    BertEncoder._STATIC_PLANS.clear()
 
 
 def host_sortable_orders(batch):

@@ -16,7 +16,8 @@ cfgp = "/tmp/hero_d4_cfg.json"
 json.dump(bench.HERO_BASE, open(cfgp, "w"))
 model = bench.build_model(dev, cfgp)
 tr = TrainStep(model, use_graph=False, static_usage=True)
-batch = make_batch("D4", vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev, videos=int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+wl = sys.argv[2] if len(sys.argv) > 2 else "D4"
+batch = make_batch(wl, vfeat_dim=bench.VFEAT, vocab=50272, seed=1, device=dev, videos=int(sys.argv[1]) if len(sys.argv) > 1 else 256)
 for _ in range(2):
     tr.micro_step(batch)
 torch.cuda.synchronize()

@@ -415,6 +415,11 @@ _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [True]       # False: one launch per weight gradient (lab A/B)
 WGRAD_BATCH = [32]          # 4: the per-layer stream-K launches of round 2 (lab A/B)
 WGRAD_DBIAS_RIDE = [True]   # False: bias gradients as (deferred) column sums of their own instead of riding on hero_wgrad_batch (lab A/B)
+# ... and only for reductions of at most this many rows (round 6, tools/lab/d4_wgrad_groups.py at config 5's 397056 rows: the tiles
+# whose loader waves also sum their dY panel run ~20 % slower, and a round of whole tiles ends with its slowest tile - 8.0-8.6 ms
+# per 256-tile launch with the QKV bias sums riding, 6.9-7.0 ms without; a column sum of their own costs 0.37 ms per layer there.
+# At the TVR batch's 12000 rows the ride costs ~5 % of the launch, the same as the sums it replaces: it stays.)
+WGRAD_RIDE_MAX_ROWS = [32768]
 B1_EPILOGUE = [False]       # True: the FFN1 bias gradient from the gelu' GEMM epilogue's fp32 atomics, as in rounds 1-3 (lab A/B)
 B1_PARTIALS = [True]        # False: round 4's ride on hero_wgrad_batch (lab A/B); True: per-tile partial sums from the gelu' epilogue
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5
@@ -573,7 +578,7 @@ def wgrad_flush():
                                       dy2.shape[1], K, K, _split_for(N, K, rows, 64 if dtype == torch.bfloat16 else 32), None)
         plan = _wgrad_plan(probs, n, rows, group[0][0].device) if dtype == torch.bfloat16 else None
         if plan is not None:
-            ride = WGRAD_DBIAS_RIDE[0]
+            ride = WGRAD_DBIAS_RIDE[0] and rows <= WGRAD_RIDE_MAX_ROWS[0]
             for i, e in enumerate(group):                   # bias gradients ride on the dY panels of the batch kernel
                 probs[i].dbias = L.ptr(e[6]) if ride else None
                 if not ride and e[6] is not None:

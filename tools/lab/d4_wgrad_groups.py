@@ -47,6 +47,8 @@ def _WQB():
     return HF._WQ_BYTES[0] >> 20
 
 
+if "noride" in sys.argv:
+    HF.WGRAD_DBIAS_RIDE[0] = False                   # bias sums as column sums of their own instead of riding on the loader waves
 HF._wgrad_plan = plan_logged
 _wf = HF.wgrad_flush
 

@@ -548,3 +548,44 @@ def test_hero_base_bf16_full_vocabulary_mlm_loss_and_tied_embedding_gradient():
     assert float(params[name].grad[50265:].abs().max()) == 0.0            # padding rows of the vocabulary get no gradient
     assert report["loss.l2"] < 2e-2 and report["loss.mean"] < 5e-3, report
     assert report["grad.word_embeddings"] < 0.06 and report["grad.lm_head.dense"] < 0.06, report
+
+
+def test_qkv_bias_gradients_with_and_without_the_ride_on_the_batched_wgrad():
+    """Round 6: the QKV bias gradients ride on hero_wgrad_batch's loader waves only for reductions of at most
+    functional.WGRAD_RIDE_MAX_ROWS rows (config 5's 397056-row launches ran 20 % slower with them, profiles/r06_d4_ride_ab.txt);
+    longer ones take the deferred column sums.  Both paths on the same HERO-base bf16 backward pass (8 videos of the D2 batch):
+    the bias gradients agree to fp32 summation order, everything else is bit-identical."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.synth import make_batch
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.set_grad_sink(None)
+    HF.clear_weight_cache()
+    _, model = hero_base()
+    b = to_dev(make_batch("D2", vocab=2048, seed=7, videos=8), "cuda")
+    keep = HF.WGRAD_RIDE_MAX_ROWS[0]
+    grads = []
+    try:
+        for cap in (keep, 0):
+            HF.WGRAD_RIDE_MAX_ROWS[0] = cap
+            model.zero_grad()
+            losses = model(b, task="tvr", compute_loss=True)
+            sum(l.sum() for l in losses).backward()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        HF.WGRAD_RIDE_MAX_ROWS[0] = keep
+        HF.clear_weight_cache()
+    ride, own = grads
+    assert set(ride) == set(own)
+    qkv_bias = [k for k in ride if k.endswith((".self.query.bias", ".self.key.bias", ".self.value.bias"))]
+    assert len(qkv_bias) == 3 * (6 + 3 + 1)                       # cross-modal, temporal and the query encoder's attention blocks
+    moved = 0
+    for k in ride:
+        if k.endswith(".bias") and not torch.equal(own[k], ride[k]):
+            moved += 1                                            # any nn.Linear bias whose sum rode on the launch (QKV, the projections)
+            # two fp32 summation orders of the same bf16 dY columns; the KEY bias gradient is a sum that cancels to ~1e-7 of the
+            # others (softmax is invariant to a constant added to every score of a row), so its relative agreement is looser
+            assert l2_err(own[k], ride[k]) < (1e-3 if k.endswith("key.bias") else 1e-5), k
+        else:
+            assert torch.equal(own[k], ride[k]), k                # every weight gradient, LayerNorm parameter, embedding table: same bits
+    assert moved >= len(qkv_bias) - 10 and all(float(ride[k].abs().max()) > 0 for k in qkv_bias)

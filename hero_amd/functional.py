@@ -415,11 +415,13 @@ _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [True]       # False: one launch per weight gradient (lab A/B)
 WGRAD_BATCH = [32]          # 4: the per-layer stream-K launches of round 2 (lab A/B)
 WGRAD_DBIAS_RIDE = [True]   # False: bias gradients as (deferred) column sums of their own instead of riding on hero_wgrad_batch (lab A/B)
-# ... and only for reductions of at most this many rows (round 6, tools/lab/d4_wgrad_groups.py at config 5's 397056 rows: the tiles
-# whose loader waves also sum their dY panel run ~20 % slower, and a round of whole tiles ends with its slowest tile - 8.0-8.6 ms
-# per 256-tile launch with the QKV bias sums riding, 6.9-7.0 ms without; a column sum of their own costs 0.37 ms per layer there.
-# At the TVR batch's 12000 rows the ride costs ~5 % of the launch, the same as the sums it replaces: it stays.)
-WGRAD_RIDE_MAX_ROWS = [32768]
+# ... and only for reductions of at most this many rows.  Round 6 (tools/lab/d4_wgrad_groups.py, tools/lab/ab_ride.py): the tiles
+# whose loader waves also sum their dY panel run ~20 % slower and a workgroup's tiles end with its slowest one - at config 5's 397056
+# rows 8.0-8.6 ms per 256-tile launch with the QKV bias sums riding against 6.9-7.0 ms without (a column sum of their own: 0.37 ms
+# per layer), the step -4.2 %; at the TVR batch's 12000 rows the ride and the deferred column sums it replaces are within 0.3 % of
+# each other (6.235 vs 6.216 ms per micro-step, ragged 8.153 vs 8.124, same process, alternating) - in favour of the sums.
+# 0 = never ride (the default since then); the kernel keeps the capability (HeroWgradProblem.dbias) and its tests.
+WGRAD_RIDE_MAX_ROWS = [0]
 B1_EPILOGUE = [False]       # True: the FFN1 bias gradient from the gelu' GEMM epilogue's fp32 atomics, as in rounds 1-3 (lab A/B)
 B1_PARTIALS = [True]        # False: round 4's ride on hero_wgrad_batch (lab A/B); True: per-tile partial sums from the gelu' epilogue
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5

@@ -364,7 +364,7 @@ def feed_ragged_run(device, rank, steps, warmup, n_batches=8, n_buckets=3):
                      "per bucket, packed cross-modal layers (static pack plan rebuilt on the host per batch)" % n_batches}
 
 
-def live_pmc(timeout_s=200):
+def live_pmc(timeout_s=75):
     """the HBM-traffic and MFMA-busy counters on the line used to be READ from a committed profile.  When
     rocprofv3 is on PATH, take them in THIS run: three short passes of this very command (2 eager micro-steps each, `--pmc`
     alone with --kernel-trace, separate passes as MI355X_MICROARCH.md prescribes) as subprocesses after the timed region,

@@ -48,6 +48,8 @@ def main():
                         bucket_bytes=64 << 10,        # small buckets -> many overlapped all-reduces
                         grad_compress=None if wire == "none" else wire)
     named = dict(model.named_parameters())
+    if len(sys.argv) > 4 and sys.argv[4] == "feeder":
+        return feeder_run(trainer, model, named, rank, world, dev, out_dir)
     # (1) parameters were broadcast from rank 0
     chk = torch.stack([p.detach().double().sum() for p in named.values()])
     both = [torch.zeros_like(chk) for _ in range(world)]
@@ -102,6 +104,38 @@ def main():
     torch.cuda.synchronize()
     json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses, "backend": dist.get_backend(), "exchange": trainer.arena.backend,
                "collectives": bool(__import__("hero_amd.utils.distributed", fromlist=["x"]).collectives_active())},
+              open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+    dist.destroy_process_group()
+
+
+def feeder_run(trainer, model, named, rank, world, dev, out_dir):
+    """Round 6: two ranks, each feeding its OWN ragged batches through a BucketedBatchFeeder (eager launches: the mode every
+    multi-rank test covers).  The buckets are derived from both ranks' batches (every padded dimension shared, the packed row
+    capacities differ), so at any step the ranks may sit on different buckets - different GEMM row counts, different pack
+    plans - while exchanging the same gradient buckets and the same padded negatives; the replicas must stay identical."""
+    from hero_amd.loader import BucketedBatchFeeder, batch_dims
+    from tests.test_gpu_loader import _ragged_batches
+    host = _ragged_batches(4, seed0=40 + 10 * rank)
+    dims = [batch_dims(h) for h in host]
+    every = [None] * world
+    dist.all_gather_object(every, dims)
+    buckets = BucketedBatchFeeder.derive_buckets([d for ds in every for d in ds], n_buckets=3, row_quantum=16)
+    feeder = BucketedBatchFeeder(buckets, dev)
+    used, losses = [], []
+    feeder.prefetch(host[0])
+    for n in range(8):
+        b = feeder.commit()
+        assert b is not None and b.get("_static_plan")
+        used.append(int(b["_bucket"]))
+        losses.append(float(trainer.micro_step(b)))
+        feeder.prefetch(host[(n + 1) % len(host)])
+    chk = torch.stack([p.detach().double().sum() for p in named.values()])
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    assert all(torch.equal(both[0], b_) for b_ in both), "replicas diverged after optimiser steps on bucketed ragged batches"
+    assert all(l == l and abs(l) < 1e4 for l in losses)
+    torch.cuda.synchronize()
+    json.dump({"rank": rank, "buckets_used": used, "n_buckets": len(buckets), "losses": losses, "backend": dist.get_backend()},
               open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
     dist.destroy_process_group()
 

@@ -246,6 +246,57 @@ def test_bucketed_feeder_streams_ragged_batches_through_a_few_graphs():
         hero_amd.set_compute_dtype(torch.bfloat16)
 
 
+def test_static_pack_plan_at_bench_size_equals_the_dynamic_plan():
+    """The static pack plan at the size and in the dtype `secondary.feed_ragged` runs it: HERO-base, bf16, the ragged D2 batch
+    (32 videos, ~14 000 valid rows) padded to a bucket with a row capacity well above its row count (pad sequences in the
+    attention launches, pad rows through every GEMM / LayerNorm / weight-gradient reduction).  Against the SAME padded batch
+    through the dynamic plan (masks read on the host, exactly the valid rows): the frame representations and the three losses
+    are bit-identical (every op between pack and unpack is row-wise or per sequence), gradients agree to fp32 summation order
+    (the weight-gradient reduction walks more - all-zero - rows)."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.loader import BucketedBatchFeeder, StaticBatchFeeder, batch_dims, pad_to_bucket, pin_batch
+    from hero_amd.model.layers import BertEncoder
+    from hero_amd.synth import make_batch
+    from tests.test_gpu_configs import GRAD_NAMES, hero_base, l2_err
+    from tests.util import to_dev
+    hero_amd.set_compute_dtype(torch.bfloat16)
+    HF.set_grad_sink(None)
+    HF.clear_weight_cache()
+    try:
+        _, model = hero_base()
+        host = make_batch("D2", vocab=2048, seed=7, ragged=True)
+        d = batch_dims(host)
+        bucket = BucketedBatchFeeder.derive_buckets([d], n_buckets=1, slack=1.05)[0]
+        bucket["rows"] = (d["rows"] // 512 + 3) * 512                       # > 1000 pad rows: ~35 pad sequences of 32 rows
+        bucket["min_rows"] = d["rows"] - 100
+        _, padded = pad_to_bucket(host, [bucket])
+        assert batch_dims(padded)["T"] == bucket["T"] >= d["T"] and bucket["rows"] - d["rows"] > 1000
+        feeder = StaticBatchFeeder(pin_batch(padded), "cuda", capture_commit=False, packed_rows=bucket["rows"], min_rows=bucket["min_rows"],
+                                   frm_capacity=bucket["frm"])
+        res = []
+        for mode, b in (("static", feeder.static), ("all", to_dev({k: v for k, v in padded.items() if k not in ("lengths", "_bucket")}, "cuda"))):
+            BertEncoder.packing_mode = mode
+            model.zero_grad()
+            with torch.no_grad():
+                frames = model.v_encoder(b, "repr")
+            losses = model(b, task="tvr", compute_loss=True)
+            sum(l.sum() for l in losses).backward()
+            params = dict(model.named_parameters())
+            res.append((frames.clone(), [float(l.detach().sum()) for l in losses], {n: params[n].grad.clone() for n in GRAD_NAMES}))
+        (f_s, l_s, g_s), (f_d, l_d, g_d) = res
+        m = padded["c_attn_masks"].bool()
+        assert torch.equal(f_s[m], f_d[m])
+        assert l_s == l_d, (l_s, l_d)
+        for n in GRAD_NAMES:
+            assert l2_err(g_s[n], g_d[n]) < 1e-4, (n, l2_err(g_s[n], g_d[n]))
+    finally:
+        BertEncoder.packing_mode = "all"
+        BertEncoder._STATIC_PLANS.clear()
+        HF.set_grad_sink(None)
+        HF.clear_weight_cache()
+
+
 def test_feeder_rejects_other_shapes():
     from hero_amd.loader import StaticBatchFeeder, pin_batch
     from hero_amd.synth import make_batch

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(SORT_NT) void segment_sort_kernel(const int32_t* __
 // token heads every subtitle: 480 rows of the TVR batch go to ONE table row - leaves one partial sum per block in the
 // workspace (slot 0: the block's first run continues from the previous block, slot 1: its last run continues into the
 // next one), and the second kernel lets the wave of the run's FIRST block add the partials up in block order.
-constexpr int SEG_B = 32;
+#ifndef HERO_SEG_B
+#define HERO_SEG_B 16            // round 6 (tools/lab/scatter_time.py, us per call: 9600 sub-tokens / the MLM batch / 480 query tokens):
+                                 // 32: 28.7 / 32.2 / 20.2   16: 24.1 / 31.0 / 13.5   8: 26.1 / 39.6 / 9.5 - more, shorter blocks put more waves in
+                                 // flight; at 8 the fold of the <mask> run (1400 rows of one id) spans too many blocks
+#endif
+constexpr int SEG_B = HERO_SEG_B;
 constexpr int UNR = 8;        // source rows (and their table rows) in flight per wave (4: 32 us per call on the bench batch, eight round trips per wave)
 __device__ __forceinline__ int seg_key(const int32_t* idx, const int32_t* order, int i, int rows, int skip) {
   if (i < 0 || i >= rows) return -2;

@@ -1207,7 +1207,7 @@ class EmbedLnFn(torch.autograd.Function):
                     folded = k_colsum(dx.view(dx.shape[0] // per, per * dx.shape[1]))
                     k_scatter_add(folded.view(per, dx.shape[1]), idx[:per], SINK.dst(tab), None, skip)
                 elif (idx.dtype == torch.int32 and idx.is_contiguous() and dx.shape[1] % 4 == 0
-                        and dx.shape[0] <= (1 << 17)):      # (beyond: a 6 KB-per-32-rows workspace; config 5 keeps the atomics)
+                        and dx.shape[0] <= (1 << 17)):      # (beyond: a 6 KB-per-16-rows workspace; config 5 keeps the atomics)
                     k_scatter_add_sorted(dx, idx.view(-1), SINK.dst(tab).view(-1, tab.shape[-1]), skip)
                 else:
                     k_scatter_add(dx, idx, SINK.dst(tab), None, skip)

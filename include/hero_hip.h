@@ -317,7 +317,7 @@ int hero_scatter_add_rows(const void* src, const int32_t* idx, void* dst_a, void
 /*   hero_segment_sort        order[rows] = the row numbers sorted by (idx[row], row), rows with idx < 0 or == skip_idx */
 /*                            last; one workgroup, stable radix sort; n_dst = rows of the table (bounds the key width); */
 /*                            workspace of hero_segment_sort_workspace_bytes(rows) bytes.  Depends on idx only: cache it. */
-/*   hero_scatter_add_sorted  blocks of 32 sorted rows, one wave each: a run of equal destinations inside a block is   */
+/*   hero_scatter_add_sorted  blocks of 16 sorted rows, one wave each: a run of equal destinations inside a block is   */
 /*                            added to dst[idx] by that wave (row order, fp32; the row has no other writer); a run that */
 /*                            crosses blocks (a token at the head of every subtitle) leaves one partial sum per block   */
 /*                            and the wave of its first block folds them in block order.  dst is fp32; cols % 4 == 0;   */

@@ -166,19 +166,42 @@ __global__ __launch_bounds__(256) void score_max_fwd_kernel(HeroScoreMax a) {
   a.out[i] = best;
   a.arg[i] = arg;
 }
-// dqn: one workgroup per query m
+// dqn: one workgroup per query m.  Round 6: the (frame, weight) pair of every video is resolved FIRST (arg -> mask -> weight is a
+// dependent chain: walked inside the accumulation loop it cost one memory round trip per video, 20 us for 32 videos), staged in
+// the LDS, and the accumulation loop then issues its row loads four videos at a time.  Same terms, same order (a zero weight adds
+// g * v = 0 exactly, rows are finite): bit-identical to the round-5 kernel.
 __global__ __launch_bounds__(256) void score_max_bwd_q_kernel(HeroScoreMax a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_q[];
+  float* sg = reinterpret_cast<float*>(smem_q);
+  int* sl = reinterpret_cast<int*>(smem_q) + a.N;
   const int m = blockIdx.x;
   const float gc = a.gc[0] * a.gc_scale, gq = a.gq[0] * a.gq_scale;
+  for (int n = threadIdx.x; n < a.N; n += 256) {
+    const int i = m * a.N + n, l = a.arg[i];
+    sl[n] = l;
+    sg[n] = (gc * a.ds_ctx[i] + gq * a.ds_q[i]) * a.mask[(size_t)n * a.L + l];
+  }
+  __syncthreads();
   for (int d = threadIdx.x * 4; d < a.D; d += 1024) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = 0; n < a.N; ++n) {
-      const int i = m * a.N + n, l = a.arg[i];
-      const float g = (gc * a.ds_ctx[i] + gq * a.ds_q[i]) * a.mask[(size_t)n * a.L + l];
-      if (g != 0.f) {
-        const float4 v = *reinterpret_cast<const float4*>(a.cn + ((size_t)n * a.L + l) * a.D + d);
-        acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
+    int n = 0;
+    for (; n + 4 <= a.N; n += 4) {
+      float4 v[4];
+      float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = sg[n + u];
+        v[u] = *reinterpret_cast<const float4*>(a.cn + ((size_t)(n + u) * a.L + sl[n + u]) * a.D + d);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x = fmaf(g[u], v[u].x, acc.x); acc.y = fmaf(g[u], v[u].y, acc.y); acc.z = fmaf(g[u], v[u].z, acc.z); acc.w = fmaf(g[u], v[u].w, acc.w);
+      }
+    }
+    for (; n < a.N; ++n) {
+      const float g = sg[n];
+      const float4 v = *reinterpret_cast<const float4*>(a.cn + ((size_t)n * a.L + sl[n]) * a.D + d);
+      acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
     }
     *reinterpret_cast<float4*>(a.dqn + (size_t)m * a.D + d) = acc;
   }
@@ -499,7 +522,8 @@ extern "C" int hero_score_max_bwd(const HeroScoreMax* a, hero_stream_t stream) {
                a->n_own, a->N);
   if (a->M <= 0 || a->N <= 0) return HERO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(score_max_bwd_q_kernel, dim3(a->M), dim3(256), 0, s, *a);
+  HERO_REQUIRE(a->N <= 4096, "hero_score_max_bwd: N = %d beyond the 4096 (weight, frame) pairs staged in the LDS", a->N);
+  hipLaunchKernelGGL(score_max_bwd_q_kernel, dim3(a->M), dim3(256), (size_t)a->N * 8, s, *a);
   int rc = check_launch("hero_score_max_bwd(q)");
   if (rc || a->n_own == 0) return rc;
   hipLaunchKernelGGL(score_max_bwd_c_kernel, dim3(a->n_own), dim3(256), 0, s, *a);

@@ -150,21 +150,31 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(HeroRowNorm a) {
 // ------------------------------------------------------------------------------------------------
 // C. mask_logits + max over the frames of a video
 // ------------------------------------------------------------------------------------------------
+// Round 6: one WAVE per (query, video) pair, a lane per frame (coalesced; the round-5 kernel gave every pair ONE thread that walked
+// its 60 frames with a load each: 13 us for 1024 pairs).  arg = the FIRST frame that attains the maximum, as a serial `>` walk finds it.
 __global__ __launch_bounds__(256) void score_max_fwd_kernel(HeroScoreMax a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= a.M * a.N) return;
   const int m = i / a.N, n = i - m * a.N;
   const float* s = a.s + (size_t)m * a.ld_s + (size_t)n * a.L;
   const float* mk = a.mask + (size_t)n * a.L;
   float best = -3.0e38f;
-  int arg = 0;
-  for (int l = 0; l < a.L; ++l) {
+  int arg = 0x7fffffff;
+  for (int l = lane; l < a.L; l += 64) {
     const float k = mk[l];
     const float v = s[l] * k + (1.f - k) * -10000.f;
-    if (v > best) { best = v; arg = l; }
+    if (v > best) { best = v; arg = l; }             // within a lane the frames come in increasing order: first maximum kept
   }
-  a.out[i] = best;
-  a.arg[i] = arg;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+  }
+  if (lane == 0) {
+    a.out[i] = best;
+    a.arg[i] = arg == 0x7fffffff ? 0 : arg;
+  }
 }
 // dqn: one workgroup per query m.  Round 6: the (frame, weight) pair of every video is resolved FIRST (arg -> mask -> weight is a
 // dependent chain: walked inside the accumulation loop it cost one memory round trip per video, 20 us for 32 videos), staged in
@@ -511,7 +521,7 @@ extern "C" int hero_score_max_fwd(const HeroScoreMax* a, hero_stream_t stream) {
   HERO_REQUIRE(a && a->s && a->mask && a->out && a->arg, "hero_score_max_fwd: null pointer");
   HERO_REQUIRE(a->L > 0 && a->ld_s >= a->N * a->L, "hero_score_max_fwd: bad L=%d / ld_s=%d", a->L, a->ld_s);
   if (a->M <= 0 || a->N <= 0) return HERO_OK;
-  hipLaunchKernelGGL(score_max_fwd_kernel, dim3((a->M * a->N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
+  hipLaunchKernelGGL(score_max_fwd_kernel, dim3((a->M * a->N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), *a);
   return check_launch("hero_score_max_fwd");
 }
 extern "C" int hero_score_max_bwd(const HeroScoreMax* a, hero_stream_t stream) {

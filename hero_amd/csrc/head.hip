@@ -325,11 +325,24 @@ __global__ __launch_bounds__(256) void st_ed_fwd_kernel(HeroStEd a) {
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* ctx = static_cast<const T*>(a.ctx) + (size_t)b * a.L * a.D;
   const float* q2 = a.q2 + (size_t)b * a.D;
-  for (int l = wave; l < a.L; l += 4) {
-    float s = 0.f;
-    for (int d = lane * 4; d < a.D; d += 256) s += dot4(V4<T>::ld(ctx + (size_t)l * a.D + d), *reinterpret_cast<const float4*>(q2 + d));
-    s = wave_sum(s);
-    if (lane == 0) { sim[l] = s; a.sim[(size_t)b * a.L + l] = s; }
+  // Round 6: four rows per trip, their loads issued together (a row per trip - load, wave sum, store behind a branch - was one
+  // memory round trip per row: 15 serial ones per wave for 60 frames, most of the kernel's 22 us).  Same sums, same order.
+  for (int l0 = wave; l0 < a.L; l0 += 16) {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = lane * 4; d < a.D; d += 256) {
+      const float4 q = *reinterpret_cast<const float4*>(q2 + d);
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = V4<T>::ld(ctx + (size_t)min(l0 + 4 * u, a.L - 1) * a.D + d);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += dot4(v[u], q);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s = wave_sum(s4[u]);
+      const int l = l0 + 4 * u;
+      if (lane == 0 && l < a.L) { sim[l] = s; a.sim[(size_t)b * a.L + l] = s; }
+    }
   }
   __syncthreads();
   const int half = a.K / 2;
@@ -429,6 +442,7 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
       if (threadIdx.x == 0) { part[k] = s0; part[MAXK + 1 + k] = s1; }
     }
     __shared__ int last_flag;
+    __shared__ float red_t[2 * (MAXK + 1)];
     if (threadIdx.x == 0) {
       __threadfence();                                                   // release: the shares above, agent scope
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (MI355X_MICROARCH.md: never let the flag overtake the write-back)
@@ -437,14 +451,30 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
       if (last_flag) { *counter = 0; __threadfence(); }                  // acquire (and leave the counter at zero)
     }
     __syncthreads();
-    if (last_flag && threadIdx.x < 2 * (MAXK + 1)) {
-      const int k = threadIdx.x % (MAXK + 1), which = threadIdx.x / (MAXK + 1);
-      if (k < a.K) {
-        float t = 0.f;
-        for (int bb = 0; bb < a.B; ++bb)
-          t += __hip_atomic_load(a.ws + (size_t)bb * (2 * (MAXK + 1)) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float* dw = which ? a.dw_ed : a.dw_st;
-        if (dw) dw[k] += t;
+    if (last_flag) {
+      // Round 6: the B shares are fetched by ALL threads at once into the LDS (thread t: element t of the [B][32] table, eight
+      // loads in flight), then 2 K threads add them up in pair order - the 32 serial agent-scope loads per thread of round 5
+      // were most of this kernel's 24 us.  Same order of additions: the same bits.
+      __shared__ float shares[64 * 2 * (MAXK + 1)];
+      constexpr int W = 2 * (MAXK + 1);
+      for (int b0 = 0; b0 < a.B; b0 += 64) {
+        const int nb = min(64, a.B - b0);
+        for (int t = threadIdx.x; t < nb * W; t += 256)
+          shares[t] = __hip_atomic_load(a.ws + (size_t)b0 * W + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x < W) {
+          const int k = threadIdx.x % (MAXK + 1), which = threadIdx.x / (MAXK + 1);
+          if (k < a.K) {
+            float t = b0 ? red_t[threadIdx.x] : 0.f;
+            for (int bb = 0; bb < nb; ++bb) t += shares[bb * W + threadIdx.x];
+            red_t[threadIdx.x] = t;
+            if (b0 + 64 >= a.B) {
+              float* dw = which ? a.dw_ed : a.dw_st;
+              if (dw) dw[k] += t;
+            }
+          }
+        }
+        __syncthreads();
       }
     }
   }
@@ -455,7 +485,19 @@ __global__ __launch_bounds__(256) void st_ed_bwd_kernel(HeroStEd a) {
   for (int d = threadIdx.x * 4; d < a.D; d += 1024) {
     const float4 q = *reinterpret_cast<const float4*>(q2 + d);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = 0; l < a.L; ++l) {
+    int l = 0;
+    for (; l + 4 <= a.L; l += 4) {                     // (round 6) four frames per trip: loads together, then the FMAs (same order) and the stores
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = V4<T>::ld(ctx + (size_t)(l + u) * a.D + d);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float s = dsim[l + u];
+        acc.x = fmaf(s, v[u].x, acc.x); acc.y = fmaf(s, v[u].y, acc.y); acc.z = fmaf(s, v[u].z, acc.z); acc.w = fmaf(s, v[u].w, acc.w);
+        V4<T>::st(dctx + (size_t)(l + u) * a.D + d, make_float4(s * q.x, s * q.y, s * q.z, s * q.w));
+      }
+    }
+    for (; l < a.L; ++l) {
       const float s = dsim[l];
       const float4 v = V4<T>::ld(ctx + (size_t)l * a.D + d);
       acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y); acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w);

@@ -1420,6 +1420,39 @@ class CsrGatherSumFn(torch.autograd.Function):
         return ds.view(ctx.sshape), None, None, None, None
 
 
+class ExpandRowsFn(torch.autograd.Function):
+    """out[r] = x[idx[r]] for an index that names rows SEVERAL times (the videos of a VSM batch with query_per_video queries each,
+    data/vsm.py:105-145: pair r = (query r, video q_vidx[r])); backward = for every source row the sum of its pairs' gradients in
+    pair order (hero_csr_gather_sum over the index sorted by source: no atomics, the same bits every run).  x: [n, ...]."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        x2 = x.reshape(x.shape[0], -1).contiguous()
+        n = x2.shape[0]
+
+        def i32():
+            return idx.reshape(-1).to(torch.int32).contiguous()
+
+        def csr():                                    # on the device, no host read: also rebuilt inside a feeder's commit graph
+            srt, order = torch.sort(idx.reshape(-1), stable=True)
+            off = torch.searchsorted(srt, torch.arange(n + 1, device=idx.device, dtype=srt.dtype))    # rows below each source
+            return torch.cat([off.to(torch.int32), order.to(torch.int32)])
+        i = memo("expand_idx", (idx,), i32, spec=(L.DERIVE_I32, 0, 0, 0))
+        ctx.csr = memo("expand_csr", (idx,), csr, (n,))
+        ctx.meta = (x.shape, n)
+        out = k_gather_rows(x2, None, i, i.numel(), x2.shape[1])
+        return out.view((i.numel(),) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, n = ctx.meta
+        d2 = dy.reshape(dy.shape[0], -1).contiguous()
+        out = torch.empty((n, d2.shape[1]), dtype=d2.dtype, device=d2.device)
+        L.check(L.lib().hero_csr_gather_sum(L.ptr(d2), L.ptr(ctx.csr[:n + 1]), L.ptr(ctx.csr[n + 1:]), L.ptr(out), n, d2.shape[1],
+                                            L.dt(d2), L.stream()))
+        return out.view(shape), None
+
+
 # ---- transformer blocks ------------------------------------------------------------------------
 # Parameters of the blocks are always leaf nn.Parameters; their gradients go to the gradient sink
 # (accumulated in place by the kernels) and the functions return None for them.

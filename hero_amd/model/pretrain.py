@@ -71,7 +71,7 @@ class HeroForPretraining(HeroModel):
                 batch["query_input_ids"], batch["query_pos_ids"], batch["query_attn_masks"],
                 attn_layer=self.q_feat_attn)
 
-        if compute_loss and self._head_is_fusable(frame_embeddings, modularized_query):
+        if compute_loss and self._head_is_fusable(frame_embeddings, modularized_query, batch):
             return self._fused_losses(batch, frame_embeddings, modularized_query)
 
         q2video_scores = st_prob = ed_prob = None
@@ -101,14 +101,20 @@ class HeroForPretraining(HeroModel):
                 self.lw_neg_q * loss_neg_q)
 
     # ------------------------------------------------------------------------------------------
-    def _head_is_fusable(self, frame_embeddings, modularized_query):
+    def _head_is_fusable(self, frame_embeddings, modularized_query, batch=None):
         """The HIP head covers the training configuration: 'mean' reduction, all in-batch negatives,
-        hinge / lse, matched (query, video) pairs, stride-1 odd kernels."""
+        hinge / lse, stride-1 odd kernels, and either matched (query, video) pairs or (round 6) query_per_video queries per
+        video (data/vsm.py:105-145).  The start / end term then runs on the pairs (query m, video q_vidx[m]) for ANY q_vidx;
+        the ranking terms take query m's video to be m // per, exactly as the reference's do (model/pretrain.py:203-264)."""
         convs = (self.video_st_predictor, self.video_ed_predictor)
         nv = frame_embeddings.shape[0] * (dist_utils.world_size() if self.gather_gpus else 1)
+        nq_, nv_ = modularized_query.shape[0], frame_embeddings.shape[0]
+        if nq_ != nv_:
+            qv = batch.get("q_vidx") if batch is not None else None
+            if qv is None or nv_ == 0 or nq_ % nv_ != 0 or qv.numel() != nq_:
+                return False
         return (self.fused_head and self.training and frame_embeddings.is_cuda and self.use_all_neg
                 and self.ranking_loss_type in ("hinge", "lse")
-                and frame_embeddings.shape[0] == modularized_query.shape[0]
                 and (nv > 1 or (self.lw_neg_ctx == 0 and self.lw_neg_q == 0))
                 and all(c.stride[0] == 1 and c.kernel_size[0] % 2 == 1 and c.kernel_size[0] <= 15
                         for c in convs))
@@ -119,7 +125,13 @@ class HeroForPretraining(HeroModel):
         cmask = batch["c_attn_masks"]
         if self.lw_st_ed != 0 and random.random() > self.drop_svmr_prob:       # model/pretrain.py:74-75
             q2 = HF.linear(modularized_query, self.video_query_linear.weight, self.video_query_linear.bias)
-            loss_st_ed = StEdLossFn.apply(q2, frame_embeddings, cmask, self.video_st_predictor.weight,
+            ctx_pairs, mask_pairs = frame_embeddings, cmask
+            if modularized_query.shape[0] != frame_embeddings.shape[0]:
+                # several queries per video: the reference scores every query against every video and keeps [row, q_vidx]
+                # (model/pretrain.py:93-99, 188-201) - the same numbers as the matched computation on the pairs
+                ctx_pairs = HF.ExpandRowsFn.apply(frame_embeddings, batch["q_vidx"])
+                mask_pairs = HF.memo("pair_mask", (cmask, batch["q_vidx"]), lambda: cmask.index_select(0, batch["q_vidx"].reshape(-1)).contiguous())
+            loss_st_ed = StEdLossFn.apply(q2, ctx_pairs, mask_pairs, self.video_st_predictor.weight,
                                           self.video_ed_predictor.weight, batch["targets"], float(self.lw_st_ed))
         if self.lw_neg_ctx != 0 or self.lw_neg_q != 0:
             qn = RowNormFn.apply(modularized_query, 1e-5)

@@ -226,3 +226,59 @@ def test_model_fused_head_with_one_ranking_weight_zero(lw):
     assert set(gf) == set(gt)
     worst = max(rel_err(gf[k], gt[k]) for k in gt if float(gt[k].abs().max()) > 1e-8)
     assert worst < 2e-4, worst
+
+
+def test_expand_rows_forward_and_backward():
+    """ExpandRowsFn (round 6): out[r] = x[idx[r]] with repeated sources; backward = the per-source sum in pair order."""
+    from hero_amd import functional as HF
+    x = rnd(5, 7, 64, seed=1).requires_grad_(True)
+    idx = torch.tensor([0, 0, 3, 1, 3, 3, 4, 0]).cuda()                 # source 2 is never referenced
+    out = HF.ExpandRowsFn.apply(x, idx)
+    assert torch.equal(out, x.detach()[idx])
+    g = rnd(8, 7, 64, seed=2)
+    out.backward(g)
+    ref = torch.zeros_like(x).index_add_(0, idx, g)
+    torch.testing.assert_close(x.grad, ref, rtol=1e-6, atol=1e-6)
+    assert float(x.grad[2].abs().sum()) == 0
+    xb = x.detach().to(torch.bfloat16).requires_grad_(True)
+    HF.ExpandRowsFn.apply(xb, idx).backward(g.to(torch.bfloat16))
+    assert rel_err(xb.grad.float(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("q_vidx", ["grouped", "shuffled"])
+@pytest.mark.parametrize("loss_type", ["hinge", "lse"])
+def test_model_fused_head_with_several_queries_per_video(q_vidx, loss_type):
+    """Round 6: the HIP head with query_per_video > 1 (data/vsm.py:105-145; BASELINE.json configs[3] has 5) == the PyTorch
+    head: three losses and every parameter gradient.  "shuffled": a q_vidx that is NOT arange // per - the start / end term
+    follows q_vidx, the ranking terms take m // per, in both heads as in the reference (model/pretrain.py:188-264)."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.utils.misc import set_dropout
+    from tests.test_oracle_golden import _vsm_batch
+    hero_amd.set_compute_dtype(torch.float32)
+    batch, _ = O.load_npz_case(os.path.join(GOLDEN, "case_pretrain.npz"))
+    b = to_dev(_vsm_batch(batch), "cuda")
+    nq, nv = b["query_input_ids"].shape[0], b["c_attn_masks"].shape[0]
+    assert nq > nv and nq % nv == 0
+    if q_vidx == "shuffled":
+        b["q_vidx"] = b["q_vidx"].flip(0).contiguous()
+        b["targets"] = torch.zeros_like(b["targets"])                    # frame 0 is valid in every video
+    res = []
+    for fused in (True, False):
+        HF.set_grad_sink(None)
+        HF.reset_caches()
+        model, _, _ = load_tiny("cuda", ranking_loss_type=loss_type)
+        model.train()
+        set_dropout(model, 0.0)
+        model.fused_head = fused
+        model.q_feat_attn.fused_pool = fused
+        assert model._head_is_fusable(torch.empty(nv, 1, 1, device="cuda"), torch.empty(nq, 1, device="cuda"), b) == fused
+        losses = model(b, task="tvr", compute_loss=True)
+        sum(l.sum() for l in losses).backward()
+        res.append(([float(l.sum()) for l in losses], {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (lf, gf), (lt, gt) = res
+    for a, c in zip(lf, lt):
+        assert abs(a - c) < 1e-5 * max(1.0, abs(c)), (lf, lt)
+    assert set(gf) == set(gt)
+    worst = max(rel_err(gf[k], gt[k]) for k in gt if float(gt[k].abs().max()) > 1e-8)
+    assert worst < 2e-4, worst

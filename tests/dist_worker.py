@@ -50,6 +50,8 @@ def main():
     named = dict(model.named_parameters())
     if len(sys.argv) > 4 and sys.argv[4] == "feeder":
         return feeder_run(trainer, model, named, rank, world, dev, out_dir)
+    if len(sys.argv) > 4 and sys.argv[4] == "multiq":
+        return multiq_run(trainer, model, named, rank, world, dev, out_dir)
     # (1) parameters were broadcast from rank 0
     chk = torch.stack([p.detach().double().sum() for p in named.values()])
     both = [torch.zeros_like(chk) for _ in range(world)]
@@ -104,6 +106,35 @@ def main():
     torch.cuda.synchronize()
     json.dump({"rank": rank, "buckets": nb, "rel_err": err, "losses": losses, "backend": dist.get_backend(), "exchange": trainer.arena.backend,
                "collectives": bool(__import__("hero_amd.utils.distributed", fromlist=["x"]).collectives_active())},
+              open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+    dist.destroy_process_group()
+
+
+def multiq_run(trainer, model, named, rank, world, dev, out_dir):
+    """Round 6: VSM batches with several queries per video (data/vsm.py:105-145) under data parallelism - the fused HIP head
+    on the (query, video) pairs with cross-rank negatives (model/pretrain.py:383-401, 427-451) == the PyTorch head: the
+    three (global) losses and, after the bucketed exchange, every gradient."""
+    from hero_amd.synth import make_pretrain_batches
+    batch = make_pretrain_batches("D1", vfeat_dim=96, vocab=160, seed=1 + rank, device=dev, queries_per_video=3)["vsm"]
+    nq, nv = batch["query_input_ids"].shape[0], batch["c_attn_masks"].shape[0]
+    assert nq == 3 * nv
+    res = []
+    for fused in (True, False):
+        model.fused_head = fused
+        model.q_feat_attn.fused_pool = fused
+        trainer.arena.zero()
+        trainer.arena.set_sync(True)
+        loss = trainer._fwd_bwd(batch)
+        trainer.arena.finish()
+        torch.cuda.synchronize()
+        res.append((float(loss), trainer.arena.flat.clone()))
+    (lf, gf), (lt, gt) = res
+    assert abs(lf - lt) < 1e-5 * max(1.0, abs(lt)), (lf, lt)
+    err = (gf - gt).abs().max().item() / max(gt.abs().max().item(), 1e-12)
+    assert err < 2e-4, "fused several-queries head != PyTorch head under cross-rank negatives (rel %g)" % err
+    both = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(both, torch.tensor([lf], device=dev, dtype=torch.float64))
+    json.dump({"rank": rank, "loss": lf, "losses_all": [float(b) for b in both], "rel_err": err, "nq": nq, "nv": nv},
               open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
     dist.destroy_process_group()
 

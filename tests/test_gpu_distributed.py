@@ -40,6 +40,19 @@ def test_two_ranks_feed_ragged_batches_through_buckets(tmp_path):
     assert len(set(res[0]["buckets_used"]) | set(res[1]["buckets_used"])) >= 2
 
 
+def test_two_ranks_several_queries_per_video_fused_head(tmp_path):
+    """Round 6: the HIP head on VSM batches with three queries per video under two-rank data parallelism (cross-rank
+    negatives gathered, gradients exchanged in buckets) == the PyTorch head; the global loss is the same on both ranks."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "none", "gloo", "multiq"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [json.load(open(tmp_path / ("rank%d.json" % k))) for k in range(2)]
+    assert res[0]["nq"] == 3 * res[0]["nv"] and res[0]["rel_err"] < 2e-4 and res[1]["rel_err"] < 2e-4
+
+
 def test_bench_plain_command_launches_two_ranks_on_one_device():
     """`python bench.py --gpus 2` as a PLAIN command (no launcher, no WORLD_SIZE): bench.py re-executes itself under
     torch.distributed.run (one process per rank on 127.0.0.1 - the driver's own N > 1 command line, which

@@ -42,6 +42,7 @@
 // Reduction tail of the O,O flavour (rows % 64 != 0): the loads of rows past the matrix are
 // out-of-range for the buffer descriptor and deliver zeros.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "gemm_ws_common.h"
 
@@ -509,9 +510,9 @@ struct WsbArgs {
   WsbProb p[HERO_WGRAD_BATCH_MAX];
 };
 
-// want_cs (loader waves of a tile with n0 == 0 and a bias gradient): the four loader waves have left their column
-// partial sums of the dY panel in the spare LDS region ([4][BM] floats); loader wave 0 folds and applies them behind the
-// first pass barrier - inside the slice-order window, so the bias gradient is as reproducible as dW.
+// want_cs (loader waves of a tile with n0 == 0 and a bias gradient): the compute waves with wn == 0 have left the column sums
+// of the tile's dY panel in the spare LDS region ([BM] floats); loader waves 0-2 apply them behind the first pass barrier -
+// inside the slice-order window, so the bias gradient is as reproducible as dW.
 template <typename G, bool COMPUTE>
 __device__ __forceinline__ void epilogue_acc(const WsbProb& P, const WsbItem& it, int* flags, char* smem, unsigned slot,
                                              f32x16_t (*acc)[G::TN], int wave, int lane, bool want_cs = false) {
@@ -581,7 +582,7 @@ __device__ __forceinline__ void epilogue_acc(const WsbProb& P, const WsbItem& it
       if (p == 0 && want_cs && tid - 256 < G::BM) {      // waves 4-6: one lane per column of the tile
         const int c = tid - 256, gm = it.m0 + c;
         const float* sp = reinterpret_cast<const float*>(smem + SPARE_OFF);
-        const float sum = (sp[c] + sp[G::BM + c]) + (sp[2 * G::BM + c] + sp[3 * G::BM + c]);
+        const float sum = sp[c];                         // parked by the compute waves of the tile (wn == 0)
         if (gm < P.M) {
           if (plain) P.colsum[gm] += sum; else atomicAdd(P.colsum + gm, sum);
         }
@@ -724,47 +725,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (second) wait_vm<G::PW>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                                     // B(-1): stage 0 landed
     unsigned slot = 0;
-    // bias gradient on the side: the tiles of the first tile column (n0 == 0) stream every row of dY[:, m0 : m0 + 192]
-    // through the LDS anyway - the loader waves, idle between their DMA issues, add the rows of each landed stage up
-    // (wave w: k-rows 16 w .. 16 w + 15 of the stage; lanes 0-47: 16-byte chunk lane % 24 of rows 2 q + lane / 24)
-    const int cchunk = lane % 24, crr = lane / 24;
+    // Bias gradients (WsbProb.colsum): the column sums of the dY panel come from the COMPUTE waves (one extra MFMA per row
+    // block against a constant selector, see below); the loader waves only apply them in the epilogue.  Rounds 4-5 had
+    // these waves add the landed stages up between their DMA issues - 24 KB more LDS reads per k-step on a loop that is
+    // bound by the LDS: the tiles that did it ran ~20 % slower and gated their round (profiles/r06_d4_ride_ab.txt).
     for (int r = next_round(0); r < g.rounds; r = next_round(r + 1)) {
       const WsbItem it = g.items[(size_t)r * nwg + wg];
       const bool want_cs = it.n0 == 0 && g.p[it.prob].colsum != nullptr;         // uniform
-      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int t = 0; t < it.nk; ++t) {
         const bool more = issue();
-        if (want_cs && lane < 48) {
-          // stage `slot` (being consumed by the compute waves in this step) landed before the previous barrier; rows past
-          // the end of the reduction were zero-filled by the buffer descriptor
-          const char* sp = smem + slot;
-          u32x4_t v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int row = 16 * w + 2 * q + crr;
-            v[q] = *reinterpret_cast<const u32x4_t*>(sp + row * (G::BM * 2) + ((cchunk ^ swz_o<G::BM * 2>(row)) << 4));
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              cs[2 * e] += __uint_as_float(v[q][e] << 16);
-              cs[2 * e + 1] += __uint_as_float(v[q][e] & 0xffff0000u);
-            }
-        }
         if (more) wait_vm<G::PW>(); else wait_vm<0>();
 #ifndef HERO_WSB_NOBAR
         __builtin_amdgcn_s_barrier();                                 // B(u)
 #endif
         if (t + 1 < it.nk) { slot += G::STAGE; if (slot == NS * G::STAGE) slot = 0; }
-      }
-      if (want_cs) {                                                    // fold the two row parities, park per wave
-        float* sp = reinterpret_cast<float*>(smem + SPARE_OFF) + w * G::BM;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float o = __shfl(cs[e], lane + 24, 64);
-          if (lane < 24) sp[cchunk * 8 + e] = cs[e] + o;
-        }
       }
 #ifndef HERO_WSB_NOEPI
       epilogue_acc<G, false>(g.p[it.prob], it, g.flags, smem, slot, nullptr, wave, lane, want_cs);
@@ -816,32 +790,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 1; i < TM; ++i) ra(i);
   };
   f32x16_t acc[TM][TN];
-  auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
+  // Bias gradient = column sums of the dY panel (the B operand a[i]: lane <-> dW row): one more MFMA per row block against
+  // a constant SELECTOR as the A operand - sel_i[mm][k] = 1 for the eight output rows mm = 8 i .. 8 i + 7, else 0 - so that
+  // rows 8 i .. 8 i + 7 of ONE extra accumulator collect block i's sums: accumulator register 4 i of lane l < 32 = the sum
+  // of column arow0 + 32 i + l of the tile.  Only the waves with wn == 0 of the tiles with n0 == 0: 3 MFMAs on top of 9 per
+  // 16-k slice on a loop whose matrix pipe is about half idle, no LDS traffic, 16 more registers.
+  f32x16_t accb;
+  unsigned selw[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) selw[i] = ((lane & 31) >> 3) == i ? 0x3f803f80u : 0u;       // two bf16 ones
+  auto mma = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN], auto cs) {
 #ifdef HERO_WSB_NOMFMA
     asm volatile("" ::"v"(a[0]), "v"(b[0]), "v"(a[TM - 1]), "v"(b[TN - 1]));
     return;
 #endif
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // dW^T: lane <-> output row
+      if constexpr (decltype(cs)::value) {
+        const u32x4_t w4 = {selw[i], selw[i], selw[i], selw[i]};
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w4), a[i], accb, 0, 0, 0);
+      }
+    }
   };
-  __builtin_amdgcn_s_setprio(2);
-  __builtin_amdgcn_s_barrier();                                       // B(-1)
-  unsigned curo = 0;
-  int r = next_round(0);
-  if (r < g.rounds) ldf(a0, b0, smem, 0);
-  while (r < g.rounds) {
-    const WsbItem it = g.items[(size_t)r * nwg + wg];
-    const int rn = next_round(r + 1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    unsigned last = curo;
-    for (int t = 0; t < it.nk; ++t) {
+  // the k-loop of one item (two instantiations: a branch inside the loop would split its scheduling regions)
+  unsigned curo = 0, last = 0;
+  auto k_loop = [&](int nk, auto cs) {
+    constexpr int NM = TM * TN + (decltype(cs)::value ? TM : 0);
+    for (int t = 0; t < nk; ++t) {
       const char* cur = smem + curo;
       last = curo;
       curo += G::STAGE;
@@ -852,16 +829,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // (round 2) the reads cost ~140 cycles of MFMA-idle issue time per slice: 0.89 us per 64-k step with the DMA
       // switched off against 0.58 us of MFMA issue (tools/lab/wsb_sweep.py, noloads).
       ldf(a1, b1, cur, 1);
-      mma(a0, b0);
-      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
+      mma(a0, b0, cs);
+      WS_INTERLEAVE(NM, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       ldf(a0, b0, cur, 2);
-      mma(a1, b1);
-      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
+      mma(a1, b1, cs);
+      WS_INTERLEAVE(NM, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       ldf(a1, b1, cur, 3);
-      mma(a0, b0);
-      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));
+      mma(a0, b0, cs);
+      WS_INTERLEAVE(NM, 2 * (TM + TN));
       __builtin_amdgcn_sched_barrier(0);
       wait_lds();
 #ifndef HERO_WSB_NOBAR
@@ -869,9 +846,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
       __builtin_amdgcn_sched_barrier(0);
       ldf(a0, b0, nxt, 0);            // unconditional (a branch around it doubles the MFMA code and spills): after the
-      mma(a1, b1);                    // item's last step this reads the landed first stage of the next item and is
-      WS_INTERLEAVE(TM * TN, 2 * (TM + TN));   // simply read again behind the epilogue
+      mma(a1, b1, cs);                // item's last step this reads the landed first stage of the next item and is
+      WS_INTERLEAVE(NM, 2 * (TM + TN));        // simply read again behind the epilogue
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_barrier();                                       // B(-1)
+  int r = next_round(0);
+  if (r < g.rounds) ldf(a0, b0, smem, 0);
+  while (r < g.rounds) {
+    const WsbItem it = g.items[(size_t)r * nwg + wg];
+    const int rn = next_round(r + 1);
+    const bool cs_on = wn == 0 && it.n0 == 0 && g.p[it.prob].colsum != nullptr;        // uniform
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    last = curo;
+    if (cs_on) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+      k_loop(it.nk, std::true_type{});
+      // park the sums for the epilogue (loader waves 0-2 apply them behind the first pass barrier)
+      float* sp = reinterpret_cast<float*>(smem + SPARE_OFF);
+      if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) sp[arow0 + 32 * i + lane] = accb[4 * i];
+      }
+    } else {
+      k_loop(it.nk, std::false_type{});
     }
     __builtin_amdgcn_s_setprio(0);
 #ifndef HERO_WSB_NOEPI

@@ -415,13 +415,14 @@ _WQ_TASK = [-1]          # autograd graph task the queued problems belong to
 GROUP_WGRADS = [True]       # False: one launch per weight gradient (lab A/B)
 WGRAD_BATCH = [32]          # 4: the per-layer stream-K launches of round 2 (lab A/B)
 WGRAD_DBIAS_RIDE = [True]   # False: bias gradients as (deferred) column sums of their own instead of riding on hero_wgrad_batch (lab A/B)
-# ... and only for reductions of at most this many rows.  Round 6 (tools/lab/d4_wgrad_groups.py, tools/lab/ab_ride.py): the tiles
-# whose loader waves also sum their dY panel run ~20 % slower and a workgroup's tiles end with its slowest one - at config 5's 397056
-# rows 8.0-8.6 ms per 256-tile launch with the QKV bias sums riding against 6.9-7.0 ms without (a column sum of their own: 0.37 ms
-# per layer), the step -4.2 %; at the TVR batch's 12000 rows the ride and the deferred column sums it replaces are within 0.3 % of
-# each other (6.235 vs 6.216 ms per micro-step, ragged 8.153 vs 8.124, same process, alternating) - in favour of the sums.
-# 0 = never ride (the default since then); the kernel keeps the capability (HeroWgradProblem.dbias) and its tests.
-WGRAD_RIDE_MAX_ROWS = [0]
+# ... and only for reductions of at most this many rows (lab A/B: 0 = never ride).  History: rounds 4-5 summed the dY panels with the
+# kernel's LOADER waves (24 KB more LDS reads per k-step on an LDS-bound loop): the tiles that did it ran ~20 % slower and gated
+# their round - config 5's 397056-row launches 8.0-8.6 ms against 6.9-7.0 without, so round 6 first took the sums out (-4.2 %
+# on config 5, +-0.3 % on the TVR batch; profiles/r06_d4_ride_ab.txt).  Round 6, late: the sums come from the COMPUTE waves - one
+# extra MFMA per row block against a constant selector operand, no LDS traffic (csrc/gemm_ws.hip) - and the ride wins at every
+# size: D2 6.070 -> 6.005 ms, ragged 7.92 -> 7.86, config 5 (256 videos) 150.3 -> 148.8 (tools/lab/ab_ride.py, same process,
+# alternating; profiles/r06_mfma_ride_ab.txt): the 55 MB re-read of dqkv per layer is gone.
+WGRAD_RIDE_MAX_ROWS = [1 << 30]
 B1_EPILOGUE = [False]       # True: the FFN1 bias gradient from the gelu' GEMM epilogue's fp32 atomics, as in rounds 1-3 (lab A/B)
 B1_PARTIALS = [True]        # False: round 4's ride on hero_wgrad_batch (lab A/B); True: per-tile partial sums from the gelu' epilogue
 WGRAD_QUEUE_BYTES = [int(os.environ.get("HERO_WGRAD_QUEUE_MB", "4096")) << 20]   # dY bytes the queue may keep alive (config 5

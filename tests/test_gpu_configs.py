@@ -551,9 +551,9 @@ def test_hero_base_bf16_full_vocabulary_mlm_loss_and_tied_embedding_gradient():
 
 
 def test_qkv_bias_gradients_with_and_without_the_ride_on_the_batched_wgrad():
-    """Round 6: the QKV bias gradients ride on hero_wgrad_batch's loader waves only for reductions of at most
-    functional.WGRAD_RIDE_MAX_ROWS rows (config 5's 397056-row launches ran 20 % slower with them, profiles/r06_d4_ride_ab.txt;
-    default 0 = never: the deferred column sums are 0.3 % faster at the TVR batch too).  Both paths on the same HERO-base bf16 backward pass (8 videos of the D2 batch):
+    """Round 6: the QKV bias gradients ride on hero_wgrad_batch (since late round 6 as one selector MFMA per row block in the
+    compute waves - the default at every size, profiles/r06_mfma_ride_ab.txt) or are deferred column sums of their own
+    (functional.WGRAD_RIDE_MAX_ROWS = 0).  Both paths on the same HERO-base bf16 backward pass (8 videos of the D2 batch):
     the bias gradients agree to fp32 summation order, everything else is bit-identical."""
     import hero_amd
     from hero_amd import functional as HF

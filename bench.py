@@ -487,8 +487,9 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed micro-steps (default 200 = a 1.2 s timed region; D4: 20 = 11 s)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed micro-steps before them (default 10; D4: 4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -513,6 +514,10 @@ def main():
                     help="N > 1: what carries the device collectives - torch.distributed's process group (default, DESIGN 6) or "
                          "hero_comm_* of the C ABI (RCCL on a side stream of this process)")
     args = ap.parse_args()
+    if args.steps is None:                           # 20 steps were a 0.125 s timed region
+        args.steps = 20 if args.workload == "D4" else 200
+    if args.warmup is None:
+        args.warmup = 4 if args.workload == "D4" else 10
 
     self_launch(args)                                # plain `python bench.py --gpus N`, N > 1: becomes the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -804,7 +809,7 @@ def main():
                     ns.videos = 256                  # step); the HBM-filling run (979 videos, 90 % of HBM) is `--workload D4`
                     r = secondary_workload(ns, device, world, rank, steps=2, warmup=2)
                 else:
-                    r = secondary_workload(ns, device, world, rank, steps=6, warmup=2)
+                    r = secondary_workload(ns, device, world, rank, steps=20, warmup=4)
                 sec[w] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "per_task", "peak_mem_gb",
                                             "step_frac_of_bf16_peak") if k in r}
                 if w == "D4":
@@ -814,12 +819,12 @@ def main():
                 sec[w] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             _forget_previous_models()
         try:
-            sec["feed"] = feed_run(device, rank, steps=20, warmup=6)       # as many timed steps as the headline run it is compared with
+            sec["feed"] = feed_run(device, rank, steps=min(args.steps, 100), warmup=6)
         except Exception as e:                           # noqa: BLE001
             sec["feed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         _forget_previous_models()
         try:
-            sec["feed_ragged"] = feed_ragged_run(device, rank, steps=20, warmup=6)
+            sec["feed_ragged"] = feed_ragged_run(device, rank, steps=min(args.steps, 60), warmup=6)
         except Exception as e:                           # noqa: BLE001
             sec["feed_ragged"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         sec["wall_s"] = round(time.perf_counter() - t_sec, 1)

@@ -939,40 +939,53 @@ def host_segment_order(ids, skip):
 def refresh_memo(sources=None, skip_outputs=()):
     """Recompute memoised derived tensors IN PLACE from the current contents of their sources.  For callers that
     rewrite batch buffers in place (hero_amd.collate.DeviceCollate, or new data copied into a captured batch):
-    captured graphs and cached maps hold the derived tensors by address.  sources: only the entries derived from one
-    of these tensors (default: every entry).  Entries with a `spec` go out together as hero_derive_multi launches."""
-    ptrs = None if sources is None else {t.data_ptr() for t in sources}
-    batch, later = [], []
+    captured graphs and cached maps hold the derived tensors by address.  sources: only the entries derived - directly or
+    through other entries - from one of these tensors (default: every entry).  Entries with a `spec` go out together as
+    hero_derive_multi launches.  Order: an entry is redone once every entry it is derived from has been (waves of a
+    topological order over the output addresses; round 6: a 0/1 mask gathered per (query, video) pair and THEN cast to fp32
+    is a spec entry behind a builder entry - the old "spec entries first" order left it one batch behind)."""
     skip_ids = {id(t) for t in skip_outputs}                  # entries the caller refreshes itself (host-computed orders)
-    if sources is not None:                                    # what this call keeps current (the caller may restamp_memo them)
-        src_ptrs = set(ptrs)
-        _LAST_REFRESHED[:] = [k for k, e in _MEMO.items() if any(t.data_ptr() in src_ptrs for t in e[1])]
     entries = [e for e in _MEMO.values() if id(e[0]) not in skip_ids]
-    # entries a hero_derive_multi launch computes (functions of ONE raw int64 batch tensor) first, then the entries with a
-    # builder of their own, which may be derived from those (segment_order sorts int32 row indices that are themselves
-    # derived from the batch's ids): a refreshed entry's output counts as a source for the entries behind it
-    for out, srcs, fn, spec in entries:
-        if spec is None or (ptrs is not None and not any(t.data_ptr() in ptrs for t in srcs)):
-            continue
-        batch.append(L.Derive(L.ptr(srcs[0]), L.ptr(out), out.numel(), spec[0], spec[1], spec[2], spec[3]))
-        if ptrs is not None:
-            ptrs.add(out.data_ptr())
-    for out, srcs, fn, spec in entries:
-        if spec is not None or (ptrs is not None and not any(t.data_ptr() in ptrs for t in srcs)):
-            continue
-        later.append((out, fn))
-        if ptrs is not None and isinstance(out, torch.Tensor):
-            ptrs.add(out.data_ptr())
-    for i in range(0, len(batch), 16):
-        part = batch[i:i + 16]
-        L.check(L.lib().hero_derive_multi((L.Derive * len(part))(*part), len(part), L.stream()))
-    for out, fn in later:
-        new = fn()
-        if isinstance(out, torch.Tensor):
-            if new.shape != out.shape:
-                raise RuntimeError("refresh_memo: a derived tensor changed shape %s -> %s; the batch structure is "
-                                   "different, not just its contents" % (tuple(out.shape), tuple(new.shape)))
-            out.copy_(new)
+    if sources is not None:                                    # what this call keeps current (the caller may restamp_memo them)
+        src_ptrs = {t.data_ptr() for t in sources}
+        _LAST_REFRESHED[:] = [k for k, e in _MEMO.items() if any(t.data_ptr() in src_ptrs for t in e[1])]
+        dirty = set(src_ptrs)
+        hit = [False] * len(entries)
+        grew = True
+        while grew:                                            # everything downstream of the sources
+            grew = False
+            for n, (out, srcs, fn, spec) in enumerate(entries):
+                if not hit[n] and any(t.data_ptr() in dirty for t in srcs):
+                    hit[n] = grew = True
+                    if isinstance(out, torch.Tensor):
+                        dirty.add(out.data_ptr())
+        todo = [e for n, e in enumerate(entries) if hit[n]]
+    else:
+        todo = list(entries)
+    waiting = {e[0].data_ptr() for e in todo if isinstance(e[0], torch.Tensor)}      # outputs not yet redone
+    while todo:
+        ready = [e for e in todo if not any(t.data_ptr() in waiting and t is not e[0] for t in e[1])]
+        if not ready:
+            raise RuntimeError("refresh_memo: memo entries derive from each other in a cycle")
+        batch = [L.Derive(L.ptr(srcs[0]), L.ptr(out), out.numel(), spec[0], spec[1], spec[2], spec[3])
+                 for out, srcs, fn, spec in ready if spec is not None]
+        for i in range(0, len(batch), 16):
+            part = batch[i:i + 16]
+            L.check(L.lib().hero_derive_multi((L.Derive * len(part))(*part), len(part), L.stream()))
+        for out, srcs, fn, spec in ready:
+            if spec is not None:
+                continue
+            new = fn()
+            if isinstance(out, torch.Tensor):
+                if new.shape != out.shape:
+                    raise RuntimeError("refresh_memo: a derived tensor changed shape %s -> %s; the batch structure is "
+                                       "different, not just its contents" % (tuple(out.shape), tuple(new.shape)))
+                out.copy_(new)
+        ids = {id(e) for e in ready}
+        for e in ready:
+            if isinstance(e[0], torch.Tensor):
+                waiting.discard(e[0].data_ptr())
+        todo = [e for e in todo if id(e) not in ids]
 
 
 _LAST_REFRESHED = []

@@ -130,7 +130,8 @@ class HeroForPretraining(HeroModel):
                 # several queries per video: the reference scores every query against every video and keeps [row, q_vidx]
                 # (model/pretrain.py:93-99, 188-201) - the same numbers as the matched computation on the pairs
                 ctx_pairs = HF.ExpandRowsFn.apply(frame_embeddings, batch["q_vidx"])
-                mask_pairs = HF.memo("pair_mask", (cmask, batch["q_vidx"]), lambda: cmask.index_select(0, batch["q_vidx"].reshape(-1)).contiguous())
+                mask_pairs = HF.memo("pair_mask", (cmask, batch["q_vidx"]),          # fp32 at once: what the head kernels read
+                                       lambda: cmask.index_select(0, batch["q_vidx"].reshape(-1)).to(torch.float32).contiguous())
             loss_st_ed = StEdLossFn.apply(q2, ctx_pairs, mask_pairs, self.video_st_predictor.weight,
                                           self.video_ed_predictor.weight, batch["targets"], float(self.lw_st_ed))
         if self.lw_neg_ctx != 0 or self.lw_neg_q != 0:

@@ -273,3 +273,30 @@ def test_static_pack_plan_is_the_dynamic_plan_plus_pad_rows():
         assert (pad >= 0).all() and pad.max() <= BE.PAD_CHUNK and int(off[-1]) == lay["rows_cap"] and len(off) == lay["n_seq"] + 1
     with pytest.raises(ValueError):
         BE.fill_static_plan(flat, dict(lay, rows_cap=valid - 1), [m.numpy() for m in masks])      # more valid rows than the capacity
+
+
+def test_refresh_memo_redoes_chained_entries_in_dependency_order():
+    """functional.refresh_memo (what a feeder's commit runs after new data landed in the static batch): entries derived from
+    OTHER entries are redone after them whatever the order of the memo table - round 6 found a (query, video) pair mask
+    (a builder entry) whose fp32 cast (an entry of its own) stayed one batch behind; restamp_memo moves re-keyed entries to
+    the end of the table, so table order is not dependency order either."""
+    from hero_amd import functional as HF
+    HF.reset_caches()
+    a = torch.arange(6, dtype=torch.int64)
+    other = torch.ones(3, dtype=torch.int64)
+    m1 = HF.memo("t1", (a,), lambda: a * 2)
+    m2 = HF.memo("t2", (m1,), lambda: m1 + 1)
+    m3 = HF.memo("t3", (m2, a), lambda: m2 * a)
+    mo = HF.memo("to", (other,), lambda: other * 7)
+    k1 = [k for k in HF._MEMO if k[0] == "t1"]
+    HF.restamp_memo(k1)                                      # t1 now sits BEHIND its dependants in the table
+    assert [k[0] for k in HF._MEMO][-1] == "t1"
+    a.copy_(torch.tensor([5, 4, 3, 2, 1, 0]))
+    other.fill_(2)
+    HF.refresh_memo(sources=[a])
+    assert torch.equal(m1, a * 2) and torch.equal(m2, a * 2 + 1) and torch.equal(m3, (a * 2 + 1) * a)
+    assert torch.equal(mo, torch.full((3,), 7))              # not derived from `a`: left alone
+    assert sorted(k[0] for k in HF.last_refreshed_keys()) == ["t1", "t3"]        # the DIRECT dependants (what a feeder restamps)
+    HF.refresh_memo()
+    assert torch.equal(mo, torch.full((3,), 14))
+    HF.reset_caches()

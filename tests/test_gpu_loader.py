@@ -109,6 +109,81 @@ def test_static_feeder_feeds_a_stream_of_batches(use_graph):
         hero_amd.set_compute_dtype(torch.bfloat16)
 
 
+def _multiq_batches(n, seed0=70, per=3):
+    """_batches with `per` queries per video (data/vsm.py:105-145); every other batch names its videos in another order
+    (q_vidx reversed: the start / end term follows q_vidx, the ranking terms take m // per, as in the reference)."""
+    from hero_amd import synth
+    out = _batches(n, seed0)
+    for k, b in enumerate(out):
+        gen = torch.Generator().manual_seed(seed0 + 100 + k)
+        nv = b["c_attn_masks"].shape[0]
+        nq = per * nv
+        b.update(synth.query_batch(nq, [12] + [int(torch.randint(4, 12, (1,), generator=gen)) for _ in range(nq - 1)], 160, gen))
+        b["targets"] = torch.stack([torch.randint(0, 5, (nq,), generator=gen), torch.randint(5, 15, (nq,), generator=gen)], 1)
+        b["q_vidx"] = torch.arange(nq) // per
+        if k % 2:
+            b["q_vidx"] = b["q_vidx"].flip(0).contiguous()
+    return out
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_static_feeder_with_several_queries_per_video(use_graph):
+    """Round 6: batches with three queries per video through the fused HIP head under StaticBatchFeeder - the (query, video)
+    pair index, its CSR for the backward and the pair mask are memoised tensors derived from q_vidx, which the feeder's
+    commit refreshes IN PLACE (inside its commit graph) when the next batch names its videos in another order."""
+    import hero_amd
+    from hero_amd import functional as HF
+    from hero_amd.loader import StaticBatchFeeder, pin_batch
+    from hero_amd.step import TrainStep
+    from hero_amd.utils.misc import set_dropout
+    from tests.util import load_tiny, to_dev
+    hero_amd.set_compute_dtype(torch.float32)
+    host = _multiq_batches(4)
+    order = [0, 1, 2, 3, 1, 0]
+
+    def fresh():
+        HF.set_grad_sink(None)
+        HF.clear_weight_cache()
+        HF.reset_caches()
+        model, _, _ = load_tiny("cuda")
+        model.train()
+        set_dropout(model, 0.0)
+        return model
+
+    try:
+        opts = dict(learning_rate=1e-3, warmup_steps=2, num_train_steps=100)
+        model = fresh()
+        nq, nv = host[0]["query_input_ids"].shape[0], host[0]["c_attn_masks"].shape[0]
+        assert model._head_is_fusable(torch.empty(nv, 1, 1, device="cuda"), torch.empty(nq, 1, device="cuda"), to_dev(host[0], "cuda"))
+        ts = TrainStep(model, opts=opts)
+        d0 = to_dev(host[0], "cuda")
+        for _ in range(4):
+            ts.micro_step(d0)
+        want = [float(ts.micro_step(to_dev(host[i], "cuda"))) for i in order]
+        assert len(set(round(w, 6) for w in want[:4])) == 4                  # the batches really differ
+        ts = TrainStep(fresh(), opts=opts, use_graph=use_graph)
+        feeder = StaticBatchFeeder(pin_batch(host[0]), "cuda")
+        if use_graph:
+            ts.prepare(feeder.static)
+        else:
+            for _ in range(4):
+                ts.micro_step(feeder.static)
+        feeder.capture()
+        pinned = [pin_batch(h) for h in host]
+        feeder.prefetch(pinned[order[0]])
+        got = []
+        for n, i in enumerate(order):
+            b = feeder.commit()
+            if n + 1 < len(order):
+                feeder.prefetch(pinned[order[n + 1]])
+            got.append(float(ts.micro_step(b)))
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-5)
+        assert torch.equal(feeder.static["q_vidx"].cpu(), host[order[-1]]["q_vidx"])
+    finally:
+        HF.set_grad_sink(None)
+        hero_amd.set_compute_dtype(torch.bfloat16)
+
+
 def _ragged_batches(n, seed0=40):
     """2 videos each, every batch its own shape: 4-8 subtitles per video, 0-4 frames and 2-9 tokens per subtitle, 18-32 frames"""
     from hero_amd import synth

@@ -41,7 +41,7 @@ def main():
               (task, total / 1e3, sum(e.device_time_total for e in other) / n / 1e3, sum(e.count for e in other) / n))
         for e in sorted(other, key=lambda e: -e.device_time_total)[:14]:
             print("   %7.1f us/step  %5.1f x  %s" % (e.device_time_total / n, e.count / n, e.key[:150]))
-        for e in sorted(ev, key=lambda e: -e.device_time_total)[:6]:
+        for e in sorted(ev, key=lambda e: -e.device_time_total)[:int(os.environ.get("TOPN", "6"))]:
             print("   top  %7.1f us/step  %5.1f x  %s" % (e.device_time_total / n, e.count / n, e.key[:120]))
 
 
